@@ -1,0 +1,73 @@
+"""TEST INFRASTRUCTURE -- mints tests/golden/*.npz from the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+Every fixture stores only seeds + the reference's outputs: weights, mels and
+the sampling noise are rebuilt from the seeds on whatever box replays them
+(``tacotronv2_wavernn_chinese_amd.synth`` is numpy-PCG64; the noise is the
+torch CPU generator stream, replayed by ``noise_from_seed`` below and guarded
+by a checksum stored in the fixture so an RNG drift is detected, not silently
+compared).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+from oracle.noise import noise_checksum
+from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+# name, mode, bits, variant, B, T, batched, target, overlap
+CASES = [
+    dict(name='raw_default_b1_t24', mode='RAW', bits=10, variant='default', B=1, T=24, batched=False),
+    dict(name='raw_peaky_b1_t24', mode='RAW', bits=10, variant='peaky', B=1, T=24, batched=False),
+    dict(name='raw_peaky_b3_t21', mode='RAW', bits=10, variant='peaky', B=3, T=21, batched=False),
+    dict(name='raw_peaky_fold_t30', mode='RAW', bits=10, variant='peaky', B=1, T=30, batched=True,
+         target=2000, overlap=200),
+    dict(name='mol_default_b1_t24', mode='MOL', bits=9, variant='default', B=1, T=24, batched=False),
+    dict(name='mol_default_b2_t21', mode='MOL', bits=9, variant='default', B=2, T=21, batched=False),
+]
+WEIGHT_SEED, MEL_SEED, NOISE_SEED = 0, 1234, 42
+
+
+def main() -> int:
+    from oracle import ref_harness as rh
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for c in CASES:
+        sd = make_state_dict(WEIGHT_SEED, mode=c['mode'], variant=c['variant'], bits=c['bits'])
+        model = rh.build_reference_model(sd, mode=c['mode'], bits=c['bits'])
+        mels = make_mels(MEL_SEED, c['B'], c['T'])
+        target, overlap = c.get('target', 11000), c.get('overlap', 550)
+        out = rh.reference_generate(model, mels, seed=NOISE_SEED, batched=c['batched'], target=target,
+                                    overlap=overlap, mu_law=True)
+        key = 'labels' if c['mode'] == 'RAW' else 'samples'
+        L, rows = out[key].shape
+        noise = rh.replay_noise(NOISE_SEED, c['mode'], L, rows, n_classes=1024)
+        up, aux = rh.reference_upsample(model, mels)
+        fix = dict(
+            mode=c['mode'], bits=c['bits'], variant=c['variant'], B=c['B'], T=c['T'],
+            batched=c['batched'], target=target, overlap=overlap,
+            weight_seed=WEIGHT_SEED, mel_seed=MEL_SEED, noise_seed=NOISE_SEED,
+            wav=out['wav'], noise_checksum=noise_checksum(noise),
+            up_head=up[:, :320], up_tail=up[:, -320:], up_stride=up[:, ::41],
+            aux_frames=aux[:, ::275],
+        )
+        if c['mode'] == 'RAW':
+            fix['labels'] = out['labels'].astype(np.int16)
+        else:
+            fix['samples'] = out['samples']
+        path = os.path.join(GOLDEN_DIR, c['name'] + '.npz')
+        np.savez_compressed(path, **fix)
+        print(f"{c['name']}: L={L} rows={rows} wav={out['wav'].shape} ref {out['seconds']:.1f}s "
+              f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
