@@ -1,0 +1,162 @@
+/*
+ * wavernn_amd.h -- C-ABI of the MI355X-native WaveRNN vocoder (mel -> wav).
+ *
+ * The reference (lturing/tacotronv2_wavernn_chinese) has NO native/FFI layer:
+ * its boundary for this path is the Python class
+ *   wavernn/models/fatchord_version.py:92-129  WaveRNN.__init__
+ *   wavernn/models/fatchord_version.py:169-264 WaveRNN.generate
+ *   wavernn/models/fatchord_version.py:414-417 WaveRNN.load  (flat state_dict)
+ * and the script wavernn_gen.py:13-43 (gen_from_file).  This header is the
+ * C-ABI a maintainer would bind from that class (ctypes stub in
+ * INTEGRATION.md); every entry point cites the reference lines it replaces.
+ *
+ * Conventions: plain pointers and sizes, no torch/C++ types; integer status
+ * returns (0 = ok, <0 = error, message via wrnn_last_error); no exceptions
+ * cross the ABI; caller allocates outputs; the library owns packed weights and
+ * scratch; one handle per device; a handle is not thread-safe, distinct
+ * handles are independent.  All `*_dev` pointers are device (HBM) pointers on
+ * the handle's device; everything is enqueued on the caller's `stream`
+ * (a hipStream_t passed as void*) and is asynchronous unless stated.
+ */
+#ifndef WAVERNN_AMD_H
+#define WAVERNN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WRNN_ABI_VERSION 1
+
+/* mode: fatchord_version.py:98-103 */
+#define WRNN_MODE_RAW 0 /* softmax over 2**bits classes */
+#define WRNN_MODE_MOL 1 /* 10-component mixture of logistics, 30 outputs */
+
+/* where the sampler's randomness comes from (fatchord_version.py:225-237,
+ * wavernn/utils/distribution.py:87-123) */
+#define WRNN_NOISE_PHILOX 0   /* device counter RNG keyed by (seed, step, row, class) */
+#define WRNN_NOISE_INJECTED 1 /* caller-supplied draws: parity protocol with the reference */
+#define WRNN_NOISE_ARGMAX 2   /* RAW only: greedy (q == 1) */
+
+/* which device implementation runs the per-sample loop */
+#define WRNN_KERNEL_AUTO 0
+#define WRNN_KERNEL_SIMPLE 1 /* one workgroup per row, weights streamed from L2/HBM */
+#define WRNN_KERNEL_TEAM 2   /* one XCD-resident team per row group, weights on chip */
+
+/* tensor dtypes accepted by wrnn_load_weights */
+#define WRNN_DTYPE_F32 0
+#define WRNN_DTYPE_I64 1
+
+#define WRNN_OK 0
+#define WRNN_ERR_INVALID -1     /* bad argument / unsupported configuration */
+#define WRNN_ERR_HIP -2         /* a HIP runtime call failed */
+#define WRNN_ERR_STATE -3       /* e.g. generate before load_weights */
+#define WRNN_ERR_MISSING_KEY -4 /* state_dict key absent (strict load) */
+#define WRNN_ERR_TIMEOUT -5     /* a bounded device spin gave up */
+
+typedef struct wrnn_handle wrnn_handle;
+
+/* Constructor arguments of WaveRNN (fatchord_version.py:93-95) + device. */
+typedef struct wrnn_config {
+    int32_t rnn_dims;            /* 512  */
+    int32_t fc_dims;             /* 512  */
+    int32_t bits;                /* 10 (RAW) */
+    int32_t pad;                 /* 2    */
+    int32_t n_upsample;          /* 3    */
+    int32_t upsample_factors[4]; /* 5,5,11 */
+    int32_t feat_dims;           /* 80   */
+    int32_t compute_dims;        /* 128  */
+    int32_t res_out_dims;        /* 128  */
+    int32_t res_blocks;          /* 10   */
+    int32_t hop_length;          /* 275  */
+    int32_t sample_rate;         /* 22050 */
+    int32_t mode;                /* WRNN_MODE_* */
+    int32_t device;              /* HIP device ordinal */
+} wrnn_config;
+
+/* One entry of the flat state_dict (fatchord_version.py:414-417; key names and
+ * shapes listed in SURVEY.md section 8a).  `data` is a HOST pointer to a
+ * contiguous row-major tensor; the library copies/repacks, the caller keeps
+ * ownership. */
+typedef struct wrnn_tensor_desc {
+    const char *name;
+    int32_t dtype; /* WRNN_DTYPE_* */
+    int32_t ndim;
+    int64_t shape[4];
+    const void *data;
+} wrnn_tensor_desc;
+
+typedef struct wrnn_sample_opts {
+    int32_t noise_mode; /* WRNN_NOISE_* */
+    int32_t kernel;     /* WRNN_KERNEL_* */
+    uint64_t seed;      /* WRNN_NOISE_PHILOX */
+    /* WRNN_NOISE_INJECTED, device pointers, step-major like the reference's
+     * RNG consumption (one sampler call per step, batch inside):
+     *   RAW: noise1 = Exp(1) draws (L, rows, n_classes)   [torch.multinomial]
+     *   MOL: noise1 = u_mix (L, rows, 10), noise2 = u_log (L, rows)          */
+    const float *noise1_dev;
+    const float *noise2_dev;
+    /* teacher forcing: value fed back as x_t instead of the drawn sample,
+     * (L, rows) device pointer or NULL */
+    const float *x_forced_dev;
+    /* optional dump of the fc3 outputs, (L, rows, n_classes) device or NULL */
+    float *logits_out_dev;
+} wrnn_sample_opts;
+
+typedef struct wrnn_timing {
+    float prologue_ms; /* conditioning kernels of the last wrnn_generate */
+    float loop_ms;     /* the per-sample loop kernel of the last wrnn_generate */
+    int32_t kernel;    /* WRNN_KERNEL_* that actually ran */
+    int32_t rows;      /* rows the loop processed (B or num_folds) */
+    int64_t steps;     /* loop length per row */
+} wrnn_timing;
+
+/* replaces WaveRNN.__init__ (fatchord_version.py:93-129) */
+int wrnn_create(const wrnn_config *cfg, wrnn_handle **out);
+
+/* replaces WaveRNN.load / load_state_dict (fatchord_version.py:414-417).
+ * strict != 0: every parameter the path needs must be present.
+ * Unknown keys (e.g. optimizer leftovers) are ignored like strict=False. */
+int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n, int32_t strict);
+
+/* Conditioning exactly as generate() builds it (fatchord_version.py:183-186:
+ * pad_tensor 'both' + UpsampleNetwork.forward :82-89), materialised:
+ *   mels_dev (B, feat, T) -> up_dev (B, T*hop, feat), aux_dev (B, T*hop, res_out)
+ * Either output may be NULL.  Used by parity tests of the prologue; the loop
+ * itself never materialises these tensors. */
+int wrnn_conditioning(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, float *up_dev,
+                      float *aux_dev, void *stream);
+
+/* Number of loop rows / steps generate() will run for (B, T, batched, target,
+ * overlap): rows = B (unbatched) or num_folds (fold_with_overlap :293-340,
+ * requires B == 1); steps = T*hop or target + 2*overlap. */
+int wrnn_plan(wrnn_handle *h, int32_t B, int32_t T, int32_t batched, int32_t target, int32_t overlap,
+              int32_t *rows_out, int64_t *steps_out);
+
+/* replaces the device part of WaveRNN.generate (fatchord_version.py:183-241):
+ * prologue + per-sample loop for all rows.
+ *   labels_out_dev  (rows, steps) int32: RAW class index | MOL mixture index (may be NULL)
+ *   samples_out_dev (rows, steps) fp32: the value appended to `output` (:227,:236)
+ * The float64 epilogue (:243-258) and the wav write (:260) stay on the host
+ * side of the binding. */
+int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, int32_t batched,
+                  int32_t target, int32_t overlap, const wrnn_sample_opts *opts, int32_t *labels_out_dev,
+                  float *samples_out_dev, void *stream);
+
+/* Blocks until the last wrnn_generate on this handle finished, then reports
+ * HIP-event timings and any device-side error (WRNN_ERR_TIMEOUT). */
+int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out);
+
+/* n_classes (fatchord_version.py:98-101) and loop-parameter bytes (roofline) */
+int32_t wrnn_n_classes(const wrnn_handle *h);
+int64_t wrnn_loop_weight_bytes(const wrnn_handle *h);
+
+const char *wrnn_last_error(const wrnn_handle *h);
+int32_t wrnn_abi_version(void);
+void wrnn_destroy(wrnn_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVERNN_AMD_H */

@@ -1,0 +1,219 @@
+"""ctypes binding of libwavernn_amd.so (C-ABI: include/wavernn_amd.h).
+
+The library is the product's only compute path: importing this module without
+a built ``csrc/libwavernn_amd.so`` raises -- there is no CPU or PyTorch
+fallback (the CPU restatement under ``oracle/`` is test infrastructure and is
+never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libwavernn_amd.so')
+
+MODE_RAW, MODE_MOL = 0, 1
+NOISE_PHILOX, NOISE_INJECTED, NOISE_ARGMAX = 0, 1, 2
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM = 0, 1, 2
+DTYPE_F32, DTYPE_I64 = 0, 1
+ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN_ERR_STATE',
+             -4: 'WRNN_ERR_MISSING_KEY', -5: 'WRNN_ERR_TIMEOUT'}
+
+# every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
+EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
+                    'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
+                    'wrnn_abi_version', 'wrnn_destroy')
+
+
+class WrnnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f'{ERR_NAMES.get(code, code)}: {msg}')
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [('rnn_dims', C.c_int32), ('fc_dims', C.c_int32), ('bits', C.c_int32), ('pad', C.c_int32),
+                ('n_upsample', C.c_int32), ('upsample_factors', C.c_int32 * 4), ('feat_dims', C.c_int32),
+                ('compute_dims', C.c_int32), ('res_out_dims', C.c_int32), ('res_blocks', C.c_int32),
+                ('hop_length', C.c_int32), ('sample_rate', C.c_int32), ('mode', C.c_int32),
+                ('device', C.c_int32)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('dtype', C.c_int32), ('ndim', C.c_int32), ('shape', C.c_int64 * 4),
+                ('data', C.c_void_p)]
+
+
+class SampleOpts(C.Structure):
+    _fields_ = [('noise_mode', C.c_int32), ('kernel', C.c_int32), ('seed', C.c_uint64),
+                ('noise1_dev', C.c_void_p), ('noise2_dev', C.c_void_p), ('x_forced_dev', C.c_void_p),
+                ('logits_out_dev', C.c_void_p)]
+
+
+class Timing(C.Structure):
+    _fields_ = [('prologue_ms', C.c_float), ('loop_ms', C.c_float), ('kernel', C.c_int32), ('rows', C.c_int32),
+                ('steps', C.c_int64)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def _preload_hip_runtime() -> str:
+    """One HIP runtime per process.  libwavernn_amd.so is linked with -no-hip-rt (no DT_NEEDED on a
+    specific libamdhip64): PyTorch-ROCm wheels bundle their own runtime, and mixing it with /opt/rocm's in
+    one process gives two HSA instances that do not share streams or events.  So: use torch's copy when
+    torch is importable (device pointers, streams and events then belong to the same runtime), else ROCm's."""
+    cands = []
+    try:
+        import torch
+        cands.append(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+    except Exception:  # pragma: no cover - torch is a hard dependency of the host side
+        pass
+    cands += ['/opt/rocm/lib/libamdhip64.so', 'libamdhip64.so']
+    for c in cands:
+        try:
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return c
+        except OSError:
+            continue
+    raise RuntimeError('no HIP runtime (libamdhip64.so) found')
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    _preload_hip_runtime()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no fallback path.')
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.wrnn_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.wrnn_create.restype = C.c_int
+    lib.wrnn_load_weights.argtypes = [vp, C.POINTER(TensorDesc), C.c_int32, C.c_int32]
+    lib.wrnn_load_weights.restype = C.c_int
+    lib.wrnn_conditioning.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.wrnn_conditioning.restype = C.c_int
+    lib.wrnn_plan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                              C.POINTER(C.c_int64)]
+    lib.wrnn_plan.restype = C.c_int
+    lib.wrnn_generate.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.POINTER(SampleOpts), vp, vp, vp]
+    lib.wrnn_generate.restype = C.c_int
+    lib.wrnn_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    lib.wrnn_last_timing.restype = C.c_int
+    lib.wrnn_n_classes.argtypes = [vp]
+    lib.wrnn_n_classes.restype = C.c_int32
+    lib.wrnn_loop_weight_bytes.argtypes = [vp]
+    lib.wrnn_loop_weight_bytes.restype = C.c_int64
+    lib.wrnn_last_error.argtypes = [vp]
+    lib.wrnn_last_error.restype = C.c_char_p
+    lib.wrnn_abi_version.argtypes = []
+    lib.wrnn_abi_version.restype = C.c_int32
+    lib.wrnn_destroy.argtypes = [vp]
+    lib.wrnn_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+class NativeVocoder:
+    """Thin owner of one ``wrnn_handle`` (one per device)."""
+
+    def __init__(self, *, rnn_dims, fc_dims, bits, pad, upsample_factors, feat_dims, compute_dims, res_out_dims,
+                 res_blocks, hop_length, sample_rate, mode, device: int):
+        self.lib = load_library()
+        cfg = Config()
+        cfg.rnn_dims, cfg.fc_dims, cfg.bits, cfg.pad = rnn_dims, fc_dims, bits, pad
+        cfg.n_upsample = len(upsample_factors)
+        for i, s in enumerate(upsample_factors):
+            cfg.upsample_factors[i] = int(s)
+        cfg.feat_dims, cfg.compute_dims, cfg.res_out_dims = feat_dims, compute_dims, res_out_dims
+        cfg.res_blocks, cfg.hop_length, cfg.sample_rate = res_blocks, hop_length, sample_rate
+        if mode not in ('RAW', 'MOL'):
+            raise RuntimeError("Unknown model mode value - ", mode)
+        cfg.mode = MODE_RAW if mode == 'RAW' else MODE_MOL
+        cfg.device = int(device)
+        self.device = int(device)
+        self.hop = int(hop_length)
+        self._h = C.c_void_p()
+        rc = self.lib.wrnn_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.wrnn_last_error(self._h).decode() if self._h else 'wrnn_create failed'
+            if self._h:
+                self.lib.wrnn_destroy(self._h)
+                self._h = C.c_void_p()
+            raise WrnnError(rc, msg)
+        self.n_classes = int(self.lib.wrnn_n_classes(self._h))
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise WrnnError(rc, self.lib.wrnn_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.wrnn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, state_dict: Dict[str, np.ndarray], strict: bool = True):
+        """state_dict: name -> contiguous numpy array (float32 / int64), reference key names."""
+        keep, descs = [], []
+        for name, arr in state_dict.items():
+            arr = np.ascontiguousarray(arr)
+            if arr.dtype == np.float32:
+                dt = DTYPE_F32
+            elif arr.dtype == np.int64:
+                dt = DTYPE_I64
+            else:
+                arr = arr.astype(np.float32)
+                dt = DTYPE_F32
+            if arr.ndim > 4:
+                continue
+            d = TensorDesc()
+            d.name = name.encode()
+            d.dtype, d.ndim = dt, arr.ndim
+            for i, s in enumerate(arr.shape):
+                d.shape[i] = s
+            d.data = arr.ctypes.data
+            keep.append(arr)
+            descs.append(d)
+        arr_t = (TensorDesc * len(descs))(*descs)
+        self._check(self.lib.wrnn_load_weights(self._h, arr_t, len(descs), 1 if strict else 0))
+        self.loop_weight_bytes = int(self.lib.wrnn_loop_weight_bytes(self._h))
+
+    def plan(self, B: int, T: int, batched: bool, target: int, overlap: int) -> Tuple[int, int]:
+        rows, steps = C.c_int32(), C.c_int64()
+        self._check(self.lib.wrnn_plan(self._h, B, T, int(bool(batched)), int(target), int(overlap),
+                                       C.byref(rows), C.byref(steps)))
+        return rows.value, steps.value
+
+    def conditioning(self, mels_ptr: int, B: int, T: int, up_ptr: int, aux_ptr: int, stream: int):
+        self._check(self.lib.wrnn_conditioning(self._h, mels_ptr, B, T, up_ptr or None, aux_ptr or None,
+                                               stream or None))
+
+    def generate(self, mels_ptr: int, B: int, T: int, batched: bool, target: int, overlap: int, *,
+                 labels_ptr: int, samples_ptr: int, stream: int, noise_mode: int = NOISE_PHILOX, seed: int = 0,
+                 noise1_ptr: int = 0, noise2_ptr: int = 0, x_forced_ptr: int = 0, logits_ptr: int = 0,
+                 kernel: int = KERNEL_AUTO):
+        o = SampleOpts()
+        o.noise_mode, o.kernel, o.seed = noise_mode, kernel, seed & 0xFFFFFFFFFFFFFFFF
+        o.noise1_dev, o.noise2_dev = noise1_ptr or None, noise2_ptr or None
+        o.x_forced_dev, o.logits_out_dev = x_forced_ptr or None, logits_ptr or None
+        self._check(self.lib.wrnn_generate(self._h, mels_ptr, B, T, int(bool(batched)), int(target), int(overlap),
+                                           C.byref(o), labels_ptr or None, samples_ptr, stream or None))
+
+    def last_timing(self) -> dict:
+        t = Timing()
+        self._check(self.lib.wrnn_last_timing(self._h, C.byref(t)))
+        return dict(prologue_ms=t.prologue_ms, loop_ms=t.loop_ms, kernel=t.kernel, rows=t.rows, steps=t.steps)

@@ -1,0 +1,225 @@
+// Prologue kernels: MelResNet (aux features) and the (5,5,11) mel upsampler.
+//
+// Reference (paths relative to /root/reference/):
+//   pad_tensor 'both'            wavernn/models/fatchord_version.py:281-291
+//   MelResNet.forward            :42-48   ResBlock.forward :21-28
+//   Stretch2d.forward            :57-61
+//   UpsampleNetwork.forward      :82-89
+//
+// Design notes (gfx950):
+//  * BatchNorm1d runs in eval mode inside generate() (:170), so it is folded
+//    into the adjacent conv weights at load time (api.hip).
+//  * MelResNet is ~0.4 MMAC per frame and runs once per utterance: one
+//    workgroup handles FT frames so every weight read is reused FT times;
+//    weights are stored [in][out] so a wavefront reads 256 contiguous bytes.
+//  * The three "stretch by s, then (2s+1)-tap conv" stages are linear and, after
+//    the `indent` crop (:88), shift-invariant (edge reach 341 samples < indent
+//    550): upsampled[t = hop*i + r, c] = sum_d ktab[r][d] * melpad[i + d, c],
+//    d < ND (= 5).  ktab is built on the host in fp64 from the learned taps.
+//    The materialising kernel below is a pure coalesced HBM writer
+//    (832 B/sample); the loop kernels never call it -- they evaluate the same
+//    5-tap form on the fly.
+#include "wrnn_internal.h"
+
+#define RESNET_FT 8      // frames per workgroup
+#define RESNET_THREADS 128
+
+// grid (ceil(T/FT), B), block 128 (thread c = output channel c; C == R == 128)
+__global__ void __launch_bounds__(RESNET_THREADS)
+resnet_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const float *__restrict__ mels, int T,
+              float *__restrict__ aux_frames) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = d.F, C = d.C, R = d.R, P = d.P, KS = d.KS;
+    const int FT = RESNET_FT;
+    float *xp = (float *)smem;             // [(FT + KS - 1)][F]  padded mel window, frame-major
+    float *xa = xp + (FT + KS - 1) * F;    // [FT][C]
+    float *xb = xa + FT * C;               // [FT][C]
+    const int b = blockIdx.y, t0 = blockIdx.x * FT, c = threadIdx.x;
+
+    // pad_tensor(..., side='both'): zeros outside [0, T)   (:281-291)
+    for (int i = threadIdx.x; i < (FT + KS - 1) * F; i += blockDim.x) {
+        const int fr = i / F, f = i - fr * F;
+        const int t = t0 + fr - P;
+        xp[i] = (t >= 0 && t < T) ? mels[((size_t)b * F + f) * T + t] : 0.0f;
+    }
+    __syncthreads();
+
+    float acc[RESNET_FT];
+    // conv_in (k = 2*pad+1, valid, no bias) + folded BN + ReLU   (:34-36,:43-45)
+    if (c < C) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f) acc[f] = 0.0f;
+        const float *wt = w + off.conv_in_t;
+        for (int fi = 0; fi < F; ++fi)
+            for (int k = 0; k < KS; ++k) {
+                const float wv = wt[(size_t)(fi * KS + k) * C + c];
+#pragma unroll
+                for (int f = 0; f < FT; ++f) acc[f] = fmaf(wv, xp[(f + k) * F + fi], acc[f]);
+            }
+        const float bv = w[off.conv_in_b + c];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) xa[f * C + c] = fmaxf(acc[f] + bv, 0.0f);
+    }
+    __syncthreads();
+    // residual blocks: x + BN2(conv2(relu(BN1(conv1(x)))))   (:21-28)
+    for (int l = 0; l < d.NBLK; ++l) {
+        if (c < C) {
+            const float *w1 = w + off.res_w1_t + (size_t)l * C * C;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f] = 0.0f;
+            for (int ci = 0; ci < C; ++ci) {
+                const float wv = w1[(size_t)ci * C + c];
+#pragma unroll
+                for (int f = 0; f < FT; ++f) acc[f] = fmaf(wv, xa[f * C + ci], acc[f]);
+            }
+            const float bv = w[off.res_b1 + (size_t)l * C + c];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) xb[f * C + c] = fmaxf(acc[f] + bv, 0.0f);
+        }
+        __syncthreads();
+        float res[RESNET_FT];
+        if (c < C) {
+            const float *w2 = w + off.res_w2_t + (size_t)l * C * C;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f] = 0.0f;
+            for (int ci = 0; ci < C; ++ci) {
+                const float wv = w2[(size_t)ci * C + c];
+#pragma unroll
+                for (int f = 0; f < FT; ++f) acc[f] = fmaf(wv, xb[f * C + ci], acc[f]);
+            }
+            const float bv = w[off.res_b2 + (size_t)l * C + c];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) res[f] = (acc[f] + bv) + xa[f * C + c];
+        }
+        __syncthreads();
+        if (c < C) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) xa[f * C + c] = res[f];
+        }
+        __syncthreads();
+    }
+    // conv_out (1x1, bias)   (:40,:47)
+    if (c < R) {
+        const float *wo = w + off.conv_out_t;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) acc[f] = 0.0f;
+        for (int ci = 0; ci < C; ++ci) {
+            const float wv = wo[(size_t)ci * R + c];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f] = fmaf(wv, xa[f * C + ci], acc[f]);
+        }
+        const float bv = w[off.conv_out_b + c];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const int t = t0 + f;
+            if (t < T) aux_frames[((size_t)b * T + t) * R + c] = acc[f] + bv;
+        }
+    }
+}
+
+hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, float *aux_frames,
+                              hipStream_t s) {
+    const WrnnDims &d = h->d;
+    dim3 grid((T + RESNET_FT - 1) / RESNET_FT, B);
+    size_t lds = ((size_t)(RESNET_FT + d.KS - 1) * d.F + 2 * (size_t)RESNET_FT * d.C) * sizeof(float);
+    hipLaunchKernelGGL(resnet_kernel, grid, dim3(RESNET_THREADS), lds, s, h->wdev, h->off, d, mels, T,
+                       aux_frames);
+    return hipGetLastError();
+}
+
+// Materialised conditioning (parity tests of rows A2-A5 only).
+//   up  (B, T*HOP, F):  up[b][t][c]  = sum_d ktab[t % HOP][d] * melpad[b][t / HOP + d][c]
+//   aux (B, T*HOP, R):  aux[b][t][:] = aux_frames[b][t / HOP][:]     (Stretch2d(total_scale,1) :70,:84)
+// grid (ceil(T*HOP / 64), B), block 256: 64 positions x (F + R = 208 channels) per block, channel fastest.
+__global__ void __launch_bounds__(256)
+materialize_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const float *__restrict__ mels,
+                   const float *__restrict__ aux_frames, int T, float *__restrict__ up,
+                   float *__restrict__ aux_up) {
+    const int F = d.F, R = d.R, HOP = d.HOP, ND = d.ND, P = d.P;
+    const int b = blockIdx.y;
+    const long L = (long)T * HOP;
+    const long t0 = (long)blockIdx.x * 64;
+    const float *ktab = w + off.ktab;
+    const int per = F + R;
+    for (int idx = threadIdx.x; idx < 64 * per; idx += blockDim.x) {
+        const int dt = idx / per, c = idx - dt * per;
+        const long t = t0 + dt;
+        if (t >= L) break;
+        const int i = (int)(t / HOP), r = (int)(t - (long)i * HOP);
+        if (c < F) {
+            if (!up) continue;
+            float acc = 0.0f;
+            for (int k = 0; k < ND; ++k) {
+                const int fr = i + k - P;  // melpad[i + k] = mel[i + k - pad], zero outside
+                const float mv = (fr >= 0 && fr < T) ? mels[((size_t)b * F + c) * T + fr] : 0.0f;
+                acc = fmaf(ktab[r * ND + k], mv, acc);
+            }
+            up[((size_t)b * L + t) * F + c] = acc;
+        } else {
+            if (!aux_up) continue;
+            const int rc = c - F;
+            aux_up[((size_t)b * L + t) * R + rc] = aux_frames[((size_t)b * T + i) * R + rc];
+        }
+    }
+}
+
+hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, const float *aux_frames, int B,
+                                   int T, float *up, float *aux_up, hipStream_t s) {
+    const WrnnDims &d = h->d;
+    const long L = (long)T * d.HOP;
+    dim3 grid((unsigned)((L + 63) / 64), B);
+    hipLaunchKernelGGL(materialize_kernel, grid, dim3(256), 0, s, h->wdev, h->off, d, mels, aux_frames, T, up,
+                       aux_up);
+    return hipGetLastError();
+}
+
+// Small per-frame linear maps that push the conditioning through the layers it feeds
+// (team kernel only): out[b][f][n] = bias[n] + sum_k in(b,f,k) * Wt[k][n].
+// grid (ceil(frames/8), ceil(N/128), B), block 128: 8 frames x 128 outputs per workgroup.
+template <int MODE>
+__global__ void __launch_bounds__(128)
+frame_linear_kernel(const float *__restrict__ src, size_t src_bstride, int ld, int valid, const float *__restrict__ Wt,
+                    int ldw, const float *__restrict__ bias, float *__restrict__ out, size_t out_bstride, int frames,
+                    int K, int N, int T, int P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xin = (float *)smem;  // [8][K]
+    const int f0 = blockIdx.x * 8, n = blockIdx.y * 128 + threadIdx.x, b = blockIdx.z;
+    const float *sb = src + (size_t)b * src_bstride;
+    for (int i = threadIdx.x; i < 8 * K; i += blockDim.x) {
+        const int ff = i / K, k = i - ff * K, f = f0 + ff;
+        float v = 0.0f;
+        if (f < frames) {
+            if (MODE == 0) { if (f < valid) v = sb[(size_t)f * ld + k]; }
+            else { const int fr = f - P; if (fr >= 0 && fr < T) v = sb[(size_t)k * T + fr]; }
+        }
+        xin[i] = v;
+    }
+    __syncthreads();
+    if (n >= N) return;
+    float acc[8];
+#pragma unroll
+    for (int ff = 0; ff < 8; ++ff) acc[ff] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float wv = Wt[(size_t)k * ldw + n];
+#pragma unroll
+        for (int ff = 0; ff < 8; ++ff) acc[ff] = fmaf(wv, xin[ff * K + k], acc[ff]);
+    }
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int ff = 0; ff < 8; ++ff)
+        if (f0 + ff < frames) out[(size_t)b * out_bstride + (size_t)(f0 + ff) * N + n] = acc[ff] + bv;
+}
+
+hipError_t wrnn_launch_frame_linear(int mode, const float *src, size_t src_bstride, int ld, int valid, const float *Wt,
+                                    int ldw, const float *bias, float *out, size_t out_bstride, int frames, int K,
+                                    int N, int B, int T, int P, hipStream_t s) {
+    dim3 grid((frames + 7) / 8, (N + 127) / 128, B);
+    const size_t lds = (size_t)8 * K * sizeof(float);
+    if (mode == 0)
+        hipLaunchKernelGGL(frame_linear_kernel<0>, grid, dim3(128), lds, s, src, src_bstride, ld, valid, Wt, ldw, bias, out,
+                           out_bstride, frames, K, N, T, P);
+    else
+        hipLaunchKernelGGL(frame_linear_kernel<1>, grid, dim3(128), lds, s, src, src_bstride, ld, valid, Wt, ldw, bias, out,
+                           out_bstride, frames, K, N, T, P);
+    return hipGetLastError();
+}

@@ -1,0 +1,166 @@
+// Internal definitions shared by the HIP translation units of libwavernn_amd.so.
+// Product code (gfx950 only).  Reference line citations are relative to
+// /root/reference/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/wavernn_amd.h"
+
+#define WRNN_MAX_UP 4
+#define WRNN_KTAB_MAXD 8
+
+// Dimensions derived from wrnn_config (WaveRNN.__init__, fatchord_version.py:93-129).
+struct WrnnDims {
+    int H;        // rnn_dims
+    int FC;       // fc_dims
+    int F;        // feat_dims
+    int A;        // aux_dims = res_out_dims / 4   (:109)
+    int C;        // compute_dims
+    int R;        // res_out_dims
+    int NBLK;     // res_blocks
+    int P;        // pad
+    int KS;       // conv_in kernel = 2*pad+1      (:33)
+    int HOP;      // prod(upsample_factors) (== hop_length)
+    int NC;       // n_classes                      (:98-101)
+    int mode;     // WRNN_MODE_*
+    int ND;       // frames of support of the composite upsampling FIR
+};
+
+// Offsets (in floats) into the single packed device allocation.
+struct WrnnPacked {
+    // prologue, BatchNorm(eval) folded into the adjacent conv (eps 1e-5)
+    size_t conv_in_t;   // [F*KS][C]
+    size_t conv_in_b;   // [C]
+    size_t res_w1_t;    // [NBLK][C(in)][C(out)]
+    size_t res_b1;      // [NBLK][C]
+    size_t res_w2_t;    // [NBLK][C][C]
+    size_t res_b2;      // [NBLK][C]
+    size_t conv_out_t;  // [C][R]
+    size_t conv_out_b;  // [R]
+    size_t ktab;        // [HOP][ND] composite (5,5,11) stretch+FIR taps
+    // loop parameters, transposed to [in][out] so that consecutive threads
+    // (= consecutive output rows) read consecutive addresses
+    size_t I_t, I_b;              // [1+F+A][H], [H]
+    size_t r1_wih_t, r1_whh_t;    // [H][3H], [H][3H]
+    size_t r1_bih, r1_bhh;        // [3H]
+    size_t r2_wih_t, r2_whh_t;    // [H+A][3H], [H][3H]
+    size_t r2_bih, r2_bhh;
+    size_t fc1_t, fc1_b;          // [H+A][FC], [FC]
+    size_t fc2_t, fc2_b;          // [FC+A][FC], [FC]
+    size_t fc3_t, fc3_b;          // [FC][NC], [NC]
+    size_t total;
+};
+
+// One loop row = one utterance (unbatched) or one fold (fold_with_overlap :293-340).
+struct WrnnRow {
+    int32_t utt;      // index into the mel batch
+    int32_t pad_;
+    int64_t start;    // first upsampled position of this row
+};
+
+struct wrnn_handle {
+    wrnn_config cfg;
+    WrnnDims d;
+    WrnnPacked off;
+    float *wdev = nullptr;        // packed weights on device
+    bool loaded = false;
+    int64_t loop_weight_bytes = 0;
+    // scratch (grown on demand)
+    float *aux_frames = nullptr;  // (B, T, R)
+    size_t aux_cap = 0;
+    WrnnRow *rows_dev = nullptr;
+    size_t rows_cap = 0;
+    unsigned *err_dev = nullptr;  // device error word (bounded spins)
+    // team kernel state
+    float *team_w = nullptr, *team_fc3 = nullptr, *wI0 = nullptr, *u1 = nullptr;
+    float *tab = nullptr;         // CM|CA|VM|VA|C2|C3|C4 for the current batch
+    size_t tab_cap = 0;
+    unsigned long long *mail = nullptr;
+    unsigned *ctl = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timing_valid = false;
+    wrnn_timing last{};
+    std::string err;
+};
+
+// Arguments of the per-sample loop kernels.
+struct WrnnLoopArgs {
+    const float *w;           // packed weights
+    WrnnPacked off;
+    WrnnDims d;
+    const float *mels;        // (B, F, T)
+    const float *aux_frames;  // (B, T, R)
+    const WrnnRow *rows;
+    int32_t n_rows;
+    int32_t T;                // mel frames per utterance
+    int64_t total_len;        // T * HOP
+    int64_t steps;            // loop length per row
+    int32_t noise_mode;
+    uint64_t seed;
+    const float *noise1;      // RAW (L, rows, NC) | MOL (L, rows, 10)
+    const float *noise2;      // MOL (L, rows)
+    const float *x_forced;    // (L, rows) or null
+    float *logits_out;        // (L, rows, NC) or null
+    int32_t *labels_out;      // (rows, L) or null
+    float *samples_out;       // (rows, L)
+    unsigned *err;
+};
+
+// Team kernel (loop_team.hip): mailbox size per team in 8-byte granules:
+// x3, fc1, fc2, race winners (2 x 512 each), gh1 (2 x 1536)
+#define WRNN_TEAM_MAIL_GRANULES (8 * 512 + 2 * 1536)
+#define WRNN_TEAM_NWREG 352
+#define WRNN_TEAM_THREADS 256
+
+struct WrnnTeamArgs {
+    const float *w;           // packed weights (biases, ktab)
+    WrnnPacked off;
+    WrnnDims d;
+    const float *team_w;      // [32 WGs][352][256 threads] register-resident weights
+    const float *team_fc3;    // [32 WGs][16384] LDS image of the fc3 slices
+    const float *wI0;         // [H]   W_I[:,0]
+    const float *u1;          // [3H]  W_ih1 . W_I[:,0]
+    // per-utterance conditioning tables pushed through the linear layers
+    const float *tabCM;       // (B, T+2P, H)   W_I[:,1:1+F] . melpad[f]
+    const float *tabCA;       // (B, T+1, H)    W_I[:,1+F:] . a1[i] + b_I         (entry T: zero conditioning)
+    const float *tabVM;       // (B, T+2P, 3H)  W_ih1 . CM[f]
+    const float *tabVA;       // (B, T+1, 3H)   W_ih1 . CA[i] + b_ih1
+    const float *tabC2;       // (B, T+1, 3H)   W_ih2[:,H:] . a2[i] + b_ih2
+    const float *tabC3;       // (B, T+1, FC)   fc1.W[:,H:] . a3[i] + b1
+    const float *tabC4;       // (B, T+1, FC)   fc2.W[:,FC:] . a4[i] + b2
+    const WrnnRow *rows;
+    int32_t n_rows;
+    int32_t n_teams;
+    int32_t T;
+    int64_t total_len;
+    int64_t steps;
+    int32_t noise_mode;
+    uint64_t seed;
+    const float *noise1;
+    const float *noise2;
+    const float *x_forced;
+    float *logits_out;
+    int32_t *labels_out;
+    float *samples_out;
+    unsigned long long *mail;  // [n_teams][WRNN_TEAM_MAIL_GRANULES]
+    unsigned *ctl;             // [16] per-XCD arrival counters
+    unsigned *err;
+};
+
+// kernels / launchers (defined in the .hip files)
+hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, float *aux_frames,
+                              hipStream_t s);
+hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, const float *aux_frames, int B,
+                                   int T, float *up, float *aux_up, hipStream_t s);
+hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
+hipError_t wrnn_launch_loop_team(const WrnnTeamArgs &a, hipStream_t s);
+// out[b][f][n] = bias[n] + sum_k in(b,f,k) * Wt[k*ldw + n]; mode 0: row-major src (rows >= valid read as 0),
+// mode 1: src = mels (B,F,T) read as zero-padded frames melpad[f] = mel[:, f - P]
+hipError_t wrnn_launch_frame_linear(int mode, const float *src, size_t src_bstride, int ld, int valid, const float *Wt,
+                                    int ldw, const float *bias, float *out, size_t out_bstride, int frames, int K,
+                                    int N, int B, int T, int P, hipStream_t s);

@@ -1,0 +1,266 @@
+"""Drop-in host side of the WaveRNN vocoder (mel -> wav) for MI355X.
+
+Mirrors the call surface of ``wavernn/models/fatchord_version.py`` of the
+reference: ``WaveRNN(rnn_dims, fc_dims, bits, pad, upsample_factors, feat_dims,
+compute_dims, res_out_dims, res_blocks, hop_length, sample_rate, mode)``
+(:93-95), ``generate(mels, save_path, batched, target, overlap, mu_law)``
+(:169-264), ``load``/``save``/``get_step``/``num_params`` (:407-429), the flat
+``state_dict`` key layout, and the reference's observable quirks (listed in
+``generate``).  The arithmetic of the hot path runs in libwavernn_amd.so (HIP,
+gfx950) through the C-ABI of ``include/wavernn_amd.h``; this module only holds
+parameters, moves pointers, and performs the float64 epilogue (:243-260).
+
+The class is an ``nn.Module`` purely as a parameter container: sub-module
+names and construction order follow the reference so that ``state_dict()``
+keys, ``load_state_dict`` and the default initialisation under a given
+``torch.manual_seed`` are interchangeable with it.  ``forward`` (teacher-forced
+training pass, :131-167) is out of scope.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from pathlib import Path
+from typing import Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _cabi
+from .dsp import decode_mu_law, save_wav
+
+
+def _bag(**mods) -> nn.Module:
+    m = nn.Module()
+    for k, v in mods.items():
+        m.add_module(k, v)
+    return m
+
+
+def _make_upsample(feat_dims, upsample_scales, compute_dims, res_blocks, res_out_dims, pad) -> nn.Module:
+    """Parameter containers with the key layout of UpsampleNetwork/MelResNet (:31-80)."""
+    resnet = nn.Module()
+    resnet.add_module('conv_in', nn.Conv1d(feat_dims, compute_dims, kernel_size=2 * pad + 1, bias=False))
+    resnet.add_module('batch_norm', nn.BatchNorm1d(compute_dims))
+    blocks = nn.ModuleList()
+    for _ in range(res_blocks):
+        blocks.append(_bag(conv1=nn.Conv1d(compute_dims, compute_dims, kernel_size=1, bias=False),
+                           conv2=nn.Conv1d(compute_dims, compute_dims, kernel_size=1, bias=False),
+                           batch_norm1=nn.BatchNorm1d(compute_dims),
+                           batch_norm2=nn.BatchNorm1d(compute_dims)))
+    resnet.add_module('layers', blocks)
+    resnet.add_module('conv_out', nn.Conv1d(compute_dims, res_out_dims, kernel_size=1))
+    up = nn.Module()
+    up.add_module('resnet', resnet)
+    layers = nn.ModuleList()
+    for s in upsample_scales:
+        layers.append(nn.Identity())  # slot of the parameter-free Stretch2d (:74)
+        conv = nn.Conv2d(1, 1, kernel_size=(1, 2 * s + 1), padding=(0, s), bias=False)
+        conv.weight.data.fill_(1. / (2 * s + 1))  # :78
+        layers.append(conv)
+    up.add_module('up_layers', layers)
+    return up
+
+
+class WaveRNN(nn.Module):
+    def __init__(self, rnn_dims, fc_dims, bits, pad, upsample_factors,
+                 feat_dims, compute_dims, res_out_dims, res_blocks,
+                 hop_length, sample_rate, mode='RAW'):
+        super().__init__()
+        self.mode = mode
+        self.pad = pad
+        if self.mode == 'RAW':
+            self.n_classes = 2 ** bits
+        elif self.mode == 'MOL':
+            self.n_classes = 30
+        else:
+            # the reference builds the exception without raising it (:102-103) and then
+            # fails on the missing n_classes; raise the same type explicitly
+            raise RuntimeError("Unknown model mode value - ", self.mode)
+        self.bits = bits
+        self.rnn_dims = rnn_dims
+        self.fc_dims = fc_dims
+        self.aux_dims = res_out_dims // 4
+        self.hop_length = hop_length
+        self.sample_rate = sample_rate
+        self._ctor = dict(rnn_dims=rnn_dims, fc_dims=fc_dims, bits=bits, pad=pad,
+                          upsample_factors=tuple(int(s) for s in upsample_factors), feat_dims=feat_dims,
+                          compute_dims=compute_dims, res_out_dims=res_out_dims, res_blocks=res_blocks,
+                          hop_length=hop_length, sample_rate=sample_rate, mode=mode)
+
+        self.upsample = _make_upsample(feat_dims, upsample_factors, compute_dims, res_blocks, res_out_dims, pad)
+        self.I = nn.Linear(feat_dims + self.aux_dims + 1, rnn_dims)
+        self.rnn1 = nn.GRU(rnn_dims, rnn_dims, batch_first=True)
+        self.rnn2 = nn.GRU(rnn_dims + self.aux_dims, rnn_dims, batch_first=True)
+        self.fc1 = nn.Linear(rnn_dims + self.aux_dims, fc_dims)
+        self.fc2 = nn.Linear(fc_dims + self.aux_dims, fc_dims)
+        self.fc3 = nn.Linear(fc_dims, self.n_classes)
+        self.register_buffer('step', torch.zeros(1, dtype=torch.long))
+        self.num_params()
+
+        # native state (created lazily, per device)
+        self._native: Optional[_cabi.NativeVocoder] = None
+        self._native_key = None
+        # knobs that are not part of the reference signature
+        self.kernel = _cabi.KERNEL_AUTO
+        self.verbose = True
+        self.last_timing: Optional[dict] = None
+
+    # ------------------------------------------------------------------ native
+    def _device_index(self) -> int:
+        dev = next(self.parameters()).device
+        if dev.type == 'cuda':
+            return dev.index if dev.index is not None else torch.cuda.current_device()
+        if not torch.cuda.is_available():
+            raise RuntimeError('WaveRNN.generate needs an MI355X (HIP) device: no GPU is visible and there is '
+                               'no CPU fallback in this package')
+        return torch.cuda.current_device()
+
+    def _weights_key(self, dev: int):
+        return (dev,) + tuple((id(p), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def native(self) -> _cabi.NativeVocoder:
+        """The wrnn_handle for the current device, repacked if parameters changed."""
+        dev = self._device_index()
+        key = self._weights_key(dev)
+        if self._native is None or self._native.device != dev:
+            if self._native is not None:
+                self._native.close()
+            self._native = _cabi.NativeVocoder(device=dev, **self._ctor)
+            self._native_key = None
+        if self._native_key != key:
+            sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+            self._native.load_weights(sd, strict=True)
+            self._native_key = key
+        return self._native
+
+    def forward(self, x, mels):
+        raise NotImplementedError('teacher-forced training forward (fatchord_version.py:131-167) is out of scope '
+                                  'of the MI355X mel->wav path')
+
+    # ---------------------------------------------------------------- generate
+    def generate_raw(self, mels, batched, target, overlap, *, noise_mode=_cabi.NOISE_PHILOX, seed=0,
+                     noise1=None, noise2=None, x_forced=None, want_logits=False, kernel=None):
+        """Device part of generate() (:183-241).  Returns dict(samples (rows, L) float32 cuda tensor,
+        labels (rows, L) int32 cuda tensor, logits or None, rows, steps).
+
+        noise1/noise2/x_forced: array-likes laid out like the reference consumes them (step-major):
+        RAW noise1 (L, rows, n_classes) Exp(1) draws; MOL noise1 (L, rows, 10), noise2 (L, rows).
+        """
+        nat = self.native()
+        dev = torch.device('cuda', nat.device)
+        with torch.cuda.device(dev):
+            mels_t = torch.as_tensor(mels).to(device=dev, dtype=torch.float32).contiguous()
+            if mels_t.dim() != 3:
+                raise ValueError(f'expected mels shaped (B, n_mels, T), got {tuple(mels_t.shape)}')
+            B, F, T = mels_t.shape
+            rows, steps = nat.plan(B, T, batched, target, overlap)
+            samples = torch.empty((rows, steps), dtype=torch.float32, device=dev)
+            labels = torch.empty((rows, steps), dtype=torch.int32, device=dev)
+            keep = []
+
+            def to_dev(a, shape):
+                if a is None:
+                    return 0
+                t = torch.as_tensor(a).to(device=dev, dtype=torch.float32).contiguous()
+                if tuple(t.shape) != shape:
+                    raise ValueError(f'expected shape {shape}, got {tuple(t.shape)}')
+                keep.append(t)
+                return t.data_ptr()
+            nmix = self.n_classes if self.mode == 'RAW' else self.n_classes // 3
+            n1 = to_dev(noise1, (steps, rows, nmix))
+            n2 = to_dev(noise2, (steps, rows))
+            xf = to_dev(x_forced, (steps, rows))
+            logits = torch.empty((steps, rows, self.n_classes), dtype=torch.float32, device=dev) if want_logits else None
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            nat.generate(mels_t.data_ptr(), B, T, batched, target, overlap,
+                         labels_ptr=labels.data_ptr(), samples_ptr=samples.data_ptr(), stream=stream,
+                         noise_mode=noise_mode, seed=int(seed), noise1_ptr=n1, noise2_ptr=n2, x_forced_ptr=xf,
+                         logits_ptr=logits.data_ptr() if logits is not None else 0,
+                         kernel=self.kernel if kernel is None else kernel)
+            self.last_timing = nat.last_timing()  # synchronises; surfaces device-side errors
+            del keep
+        return dict(samples=samples, labels=labels, logits=logits, rows=rows, steps=steps)
+
+    def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law, **native_opts):
+        """Same contract as the reference ``generate`` (:169-264), including its quirks:
+        generates T*hop samples but returns (T-1)*hop (:184,:257); raises ``ValueError`` for T < 21
+        (fade-out broadcast, :256-258); an unbatched call with B > 1 returns only utterance 0 (:253);
+        batched mode needs B == 1 (:338); MOL forces ``mu_law=False`` (:174); the return value is float64
+        (:245); the model is left in train mode (:262) and a wav is always written (:260).
+        Sampling draws from a device counter RNG seeded from the global torch generator, so
+        ``torch.manual_seed`` makes a call reproducible like it does for the reference.
+        """
+        self.eval()
+        mu_law = mu_law if self.mode == 'RAW' else False
+        start = time.time()
+        mels_t = torch.as_tensor(mels)
+        wave_len = (mels_t.size(-1) - 1) * self.hop_length
+        if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) == _cabi.NOISE_PHILOX:
+            native_opts['seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
+        res = self.generate_raw(mels_t, batched, target, overlap, **native_opts)
+        output = res['samples'].cpu().numpy().astype(np.float64)  # (rows, L)   :243-245
+        if self.verbose:
+            self.gen_display(res['steps'] - 1, res['steps'], res['rows'], start)
+
+        if mu_law:
+            output = decode_mu_law(output, self.n_classes, False)
+        if batched:
+            output = self.xfade_and_unfold(output, target, overlap)
+        else:
+            output = output[0]
+
+        # Fade-out at the end to avoid signal cutting out suddenly   (:255-258)
+        fade_out = np.linspace(1, 0, 20 * self.hop_length)
+        output = output[:wave_len]
+        output[-20 * self.hop_length:] *= fade_out
+
+        save_wav(output, save_path, self.sample_rate)
+        self.train()
+        return output
+
+    def gen_display(self, i, seq_len, b_size, start):
+        """The reference's own ksamples/s meter (:267-271)."""
+        gen_rate = (i + 1) / (time.time() - start) * b_size / 1000
+        sys.stdout.write(f'\r| {(i + 1) * b_size}/{seq_len * b_size} | Batch Size: {b_size} | '
+                         f'Gen Rate: {gen_rate:.1f}kHz | ')
+
+    def xfade_and_unfold(self, y, target, overlap):
+        """Equal-power crossfade + overlap-add of the folds (:342-405), float64 on the host."""
+        num_folds, length = y.shape
+        target = length - 2 * overlap
+        total_len = num_folds * (target + overlap) + overlap
+        silence_len = overlap // 2
+        fade_len = overlap - silence_len
+        ramp = np.linspace(-1, 1, fade_len, dtype=np.float64)
+        fade_in = np.concatenate([np.zeros(silence_len, dtype=np.float64), np.sqrt(0.5 * (1 + ramp))])
+        fade_out = np.concatenate([np.ones(silence_len, dtype=np.float64), np.sqrt(0.5 * (1 - ramp))])
+        y[:, :overlap] *= fade_in
+        y[:, -overlap:] *= fade_out
+        unfolded = np.zeros(total_len, dtype=np.float64)
+        for i in range(num_folds):
+            lo = i * (target + overlap)
+            unfolded[lo:lo + target + 2 * overlap] += y[i]
+        return unfolded
+
+    # ------------------------------------------------------------ bookkeeping
+    def get_step(self):
+        return self.step.data.item()
+
+    def log(self, path, msg):
+        with open(path, 'a') as f:
+            print(msg, file=f)
+
+    def load(self, path: Union[str, Path]):
+        device = next(self.parameters()).device
+        self.load_state_dict(torch.load(path, map_location=device), strict=False)
+
+    def save(self, path: Union[str, Path]):
+        torch.save(self.state_dict(), path)
+
+    def num_params(self, print_out=True):
+        n = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad) / 1_000_000
+        if print_out:
+            print('Trainable Parameters: %.3fM' % n)
+        return n

@@ -1,0 +1,61 @@
+"""Comparison rules for the GPU path vs the oracle (see DESIGN.md "parity protocol").
+
+The sampler is a race: argmax_k p_k / q_k over 1024 classes (torch.multinomial's n=1 path).  Two
+correct fp32 implementations that sum in a different order can legitimately disagree when the two
+best race scores are (nearly) tied, and in a free-running generation everything after such a step is
+a different -- equally valid -- trajectory.  So:
+  * teacher-forced (P0): at EVERY step the GPU label must equal the oracle label, or the step must be a
+    near-tie (oracle's relative margin < NEAR_TIE) and the GPU must have picked the oracle's runner-up;
+  * free-running (P1): labels must be identical up to the first such near-tie (if any).
+With identical labels the fed-back value is bit-identical, which is stricter than the +-1 LSB the
+north star asks for.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+NEAR_TIE = 1e-4       # RAW: relative gap of the two best p/q scores
+NEAR_TIE_MOL = 1e-4   # MOL: absolute gap of the two best Gumbel scores
+MOL_LSB = 2.0 / (2 ** 9 - 1)
+
+
+def check_teacher_forced_raw(got, ref):
+    """got (L, rows) int; ref: oracle dict with labels/margin/runner (L, rows)."""
+    bad = np.argwhere(got != ref['labels'])
+    for t, r in bad:
+        assert ref['margin'][t, r] < NEAR_TIE and got[t, r] == ref['runner'][t, r], \
+            f'step {t} row {r}: gpu {got[t, r]} oracle {ref["labels"][t, r]} margin {ref["margin"][t, r]:.3e}'
+    return len(bad)
+
+
+def check_free_run_raw(got, ref):
+    """Identical until the first near-tie.  Returns list of first-divergence steps per row (None = none)."""
+    first = []
+    for r in range(got.shape[1]):
+        mism = np.flatnonzero(got[:, r] != ref['labels'][:, r])
+        if mism.size == 0:
+            first.append(None)
+            continue
+        t = int(mism[0])
+        assert ref['margin'][t, r] < NEAR_TIE and got[t, r] == ref['runner'][t, r], \
+            f'row {r}: first divergence at step {t} is not a near-tie (margin {ref["margin"][t, r]:.3e})'
+        first.append(t)
+    return first
+
+
+def check_mol(got_samples, got_mix, ref, teacher_forced):
+    """MOL: continuous sample within one 9-bit LSB (in practice ~1e-6) wherever the mixture index agrees;
+    a mixture-index disagreement must be a near-tie."""
+    L, rows = got_samples.shape
+    for r in range(rows):
+        mism = np.flatnonzero(got_mix[:, r] != ref['labels'][:, r])
+        for t in mism:
+            assert ref['margin'][t, r] < NEAR_TIE_MOL and got_mix[t, r] == ref['runner'][t, r], \
+                f'row {r} step {t}: mixture index differs and is not a near-tie'
+        end = L if (teacher_forced or mism.size == 0) else int(mism[0])
+        ok = np.ones(L, bool)
+        ok[mism] = False
+        ok[end:] = False
+        err = np.abs(got_samples[ok, r] - ref['samples'][ok, r])
+        assert err.size == 0 or err.max() <= 1e-4, f'row {r}: max sample error {err.max():.3e}'
+        assert err.size == 0 or err.max() < MOL_LSB

@@ -1,0 +1,196 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the reference's golden vectors.
+Runs on the MI355X box only (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.golden_util import ALL_CASES, MOL_CASES, RAW_CASES, load_case
+from tests.parity_util import check_free_run_raw, check_mol, check_teacher_forced_raw
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ['team', 'simple']
+
+
+def _model(fx, kernel='simple'):
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS
+    from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+    dims = dict(DEFAULT_DIMS)
+    dims['bits'] = int(fx['bits'])
+    m = WaveRNN(**dims, mode=fx['mode'])
+    m.verbose = False
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in fx['state_dict'].items()})
+    m.to('cuda:0')
+    m.kernel = {'simple': _cabi.KERNEL_SIMPLE, 'team': _cabi.KERNEL_TEAM, 'auto': _cabi.KERNEL_AUTO}[kernel]
+    return m
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle(fx, x_forced=None, want_logits=False):
+    """Oracle runs are cached per (case, free/forced): they are CPU seconds the GPU box pays for."""
+    key = (fx['name'], x_forced is not None)
+    hit = _ORACLE_CACHE.get(key)
+    if hit is not None and (hit['logits'] is not None or not want_logits):
+        return hit
+    out = _oracle_run(fx, x_forced, True)
+    _ORACLE_CACHE[key] = out
+    return out
+
+
+def _oracle_run(fx, x_forced=None, want_logits=False):
+    om = orc.OracleModel(fx['state_dict'], mode=fx['mode'], bits=int(fx['bits']))
+    cm, ca = om.conditioning(fx['mels'])
+    if fx['batched']:
+        cm = om.fold(cm, int(fx['target']), int(fx['overlap']))
+        ca = om.fold(ca, int(fx['target']), int(fx['overlap']))
+    if fx['mode'] == 'RAW':
+        return om.loop(cm, ca, orc.NOISE_EXPO, fx['noise']['expo'], x_forced=x_forced, want_logits=want_logits)
+    return om.loop(cm, ca, 0, fx['noise']['u_mix'], fx['noise']['u_log'], x_forced=x_forced, want_logits=want_logits)
+
+
+def _noise_kwargs(fx):
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    if fx['mode'] == 'RAW':
+        return dict(noise_mode=_cabi.NOISE_INJECTED, noise1=fx['noise']['expo'])
+    return dict(noise_mode=_cabi.NOISE_INJECTED, noise1=fx['noise']['u_mix'], noise2=fx['noise']['u_log'])
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_conditioning_matches_reference(name):
+    """Rows A2-A5: pad + MelResNet + (5,5,11) upsample vs the reference's own tensors."""
+    fx = load_case(name)
+    m = _model(fx)
+    nat = m.native()
+    B, F, T = fx['mels'].shape
+    L = T * 275
+    mels = torch.from_numpy(fx['mels']).cuda()
+    up = torch.empty((B, L, 80), device='cuda')
+    aux = torch.empty((B, L, 128), device='cuda')
+    nat.conditioning(mels.data_ptr(), B, T, up.data_ptr(), aux.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    up, aux = up.cpu().numpy(), aux.cpu().numpy()
+    np.testing.assert_allclose(up[:, :320], fx['up_head'], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(up[:, -320:], fx['up_tail'], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(up[:, ::41], fx['up_stride'], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(aux[:, ::275], fx['aux_frames'], rtol=0, atol=2e-5)
+    # nearest-neighbour stretch of aux: constant inside a frame
+    np.testing.assert_array_equal(aux[:, 0:275], np.repeat(aux[:, :1], 275, axis=1))
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('name', RAW_CASES)
+def test_raw_teacher_forced_every_step(name, kernel):
+    fx = load_case(name)
+    free = _oracle(fx)
+    # the reference's own labels are the golden truth for the fed-back sequence
+    np.testing.assert_array_equal(free['labels'], fx['labels'].astype(np.int32))
+    ref = _oracle(fx, x_forced=free['samples'], want_logits=True)
+    m = _model(fx, kernel)
+    res = m.generate_raw(fx['mels'], bool(fx['batched']), int(fx['target']), int(fx['overlap']),
+                         x_forced=free['samples'], want_logits=True, **_noise_kwargs(fx))
+    got = res['labels'].cpu().numpy().T
+    nbad = check_teacher_forced_raw(got, ref)
+    assert nbad <= max(2, got.size // 2000)
+    lg = res['logits'].cpu().numpy()
+    scale = max(1.0, float(np.abs(ref['logits']).max()))
+    assert np.abs(lg - ref['logits']).max() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('name', RAW_CASES)
+def test_raw_free_running_matches_reference_labels(name, kernel):
+    fx = load_case(name)
+    ref = _oracle(fx)
+    m = _model(fx, kernel)
+    res = m.generate_raw(fx['mels'], bool(fx['batched']), int(fx['target']), int(fx['overlap']), **_noise_kwargs(fx))
+    got = res['labels'].cpu().numpy().T
+    first = check_free_run_raw(got, ref)
+    # samples are the label mapped to [-1, 1] exactly like fatchord_version.py:235
+    smp = res['samples'].cpu().numpy().T
+    np.testing.assert_array_equal(smp, (2.0 * got.astype(np.float32) / np.float32(1023.0) - np.float32(1.0)))
+    if all(f is None for f in first):
+        np.testing.assert_array_equal(got, fx['labels'].astype(np.int32))
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('name', MOL_CASES)
+def test_mol_parity(name, kernel):
+    fx = load_case(name)
+    m = _model(fx, kernel)
+    ref = _oracle(fx)
+    np.testing.assert_allclose(ref['samples'], fx['samples'], rtol=0, atol=2e-6)
+    res = m.generate_raw(fx['mels'], False, 11000, 550, **_noise_kwargs(fx))
+    check_mol(res['samples'].cpu().numpy().T, res['labels'].cpu().numpy().T, ref, teacher_forced=False)
+    reft = _oracle(fx, x_forced=ref['samples'])
+    res = m.generate_raw(fx['mels'], False, 11000, 550, x_forced=ref['samples'], **_noise_kwargs(fx))
+    check_mol(res['samples'].cpu().numpy().T, res['labels'].cpu().numpy().T, reft, teacher_forced=True)
+
+
+@pytest.mark.parametrize('name', ['raw_peaky_b1_t24', 'raw_peaky_fold_t30', 'raw_peaky_b3_t21', 'mol_default_b1_t24'])
+def test_generate_end_to_end_wav(name, tmp_path):
+    """The full drop-in call: generate() return value vs the reference's own wav (float64)."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    fx = load_case(name)
+    m = _model(fx)
+    out = tmp_path / 'o.wav'
+    wav = m.generate(fx['mels'], out, bool(fx['batched']), int(fx['target']), int(fx['overlap']), True,
+                     **_noise_kwargs(fx))
+    assert wav.dtype == np.float64 and wav.shape == fx['wav'].shape
+    assert m.training  # the reference leaves the module in train mode (:262)
+    assert out.exists()
+    ref = _oracle(fx)
+    res = m.generate_raw(fx['mels'], bool(fx['batched']), int(fx['target']), int(fx['overlap']), **_noise_kwargs(fx))
+    if fx['mode'] == 'RAW':
+        same = all(f is None for f in check_free_run_raw(res['labels'].cpu().numpy().T, ref))
+        if same:
+            np.testing.assert_array_equal(wav, fx['wav'])
+    else:
+        if (res['labels'].cpu().numpy().T == ref['labels']).all():
+            np.testing.assert_allclose(wav, fx['wav'], rtol=0, atol=1e-4)
+
+
+def test_quirks():
+    fx = load_case('raw_peaky_b1_t24')
+    m = _model(fx)
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels
+    # T < 21: the reference dies in the fade-out broadcast (fatchord_version.py:256-258)
+    with pytest.raises(ValueError):
+        m.generate(make_mels(1, 1, 20), '/tmp/wrnn_q.wav', False, 11000, 550, True)
+    # batched needs a single utterance (fold_with_overlap, :338)
+    with pytest.raises(_cabi.WrnnError):
+        m.generate(make_mels(1, 2, 30), '/tmp/wrnn_q.wav', True, 2000, 200, True)
+    # philox mode: reproducible under torch.manual_seed, different across seeds
+    torch.manual_seed(5)
+    a = m.generate(make_mels(2, 1, 21), '/tmp/wrnn_q.wav', False, 11000, 550, True)
+    torch.manual_seed(5)
+    b = m.generate(make_mels(2, 1, 21), '/tmp/wrnn_q.wav', False, 11000, 550, True)
+    torch.manual_seed(6)
+    c = m.generate(make_mels(2, 1, 21), '/tmp/wrnn_q.wav', False, 11000, 550, True)
+    np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(a, c)
+
+
+def test_philox_sampling_is_distributionally_correct():
+    """Own-RNG production mode: the kernel's draws are reproduced on the host (same Philox, numpy) and
+    injected into the oracle -> same labels (near-tie rule)."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tests.philox_ref import philox_uniform
+    fx = load_case('raw_peaky_b1_t24')
+    m = _model(fx)
+    seed = 0x1234ABCD5678
+    res = m.generate_raw(fx['mels'], False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=seed)
+    got = res['labels'].cpu().numpy().T
+    L = got.shape[0]
+    u = philox_uniform(seed, L, 1, 1024)
+    q = (-np.log(u.astype(np.float64))).astype(np.float32)
+    om = orc.OracleModel(fx['state_dict'])
+    cm, ca = om.conditioning(fx['mels'])
+    ref = om.loop(cm, ca, orc.NOISE_EXPO, q)
+    check_free_run_raw(got, ref)
+    # and the histogram is not degenerate
+    assert len(np.unique(got)) > 50
