@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -313,6 +314,7 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
     if (!h->mail) {
         HIP_TRY(h, hipMalloc(&h->mail, (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->ctl, 64));
+        if (getenv("WRNN_TEAM_PROF")) { HIP_TRY(h, hipMalloc(&h->prof, 8 * 17 * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->prof, 0, 8 * 17 * sizeof(unsigned long long))); }
     }
     if (h->wdev) { (void)hipFree(h->wdev); h->wdev = nullptr; }
     HIP_TRY(h, hipMalloc(&h->wdev, o.total * sizeof(float)));
@@ -412,19 +414,21 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));
     } else if (kernel == WRNN_KERNEL_TEAM) {
+        if (d.ND != 5 || d.HOP > 275) return fail(h, WRNN_ERR_INVALID, "team kernel is built for pad=2 (5-frame upsampling support), hop <= 275");
         // conditioning pushed through the linear layers it feeds (once per call)
         const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, P = d.P;
         const int TP = T + 2 * P, T1 = T + 1;
         const size_t nCM = (size_t)B * TP * H, nCA = (size_t)B * T1 * H, nVM = (size_t)B * TP * 3 * H, nVA = (size_t)B * T1 * 3 * H;
         const size_t nC2 = (size_t)B * T1 * 3 * H, nC3 = (size_t)B * T1 * FC, nC4 = (size_t)B * T1 * FC;
-        const size_t need = nCM + nCA + nVM + nVA + nC2 + nC3 + nC4;
+        const size_t nREC = (size_t)B * T1 * H * 28;
+        const size_t need = nCM + nCA + nVM + nVA + nC2 + nC3 + nC4 + nREC;
         if (need > h->tab_cap) {
             if (h->tab) (void)hipFree(h->tab);
             h->tab = nullptr; h->tab_cap = 0;
             HIP_TRY(h, hipMalloc(&h->tab, need * sizeof(float)));
             h->tab_cap = need;
         }
-        float *tCM = h->tab, *tCA = tCM + nCM, *tVM = tCA + nCA, *tVA = tVM + nVM, *tC2 = tVA + nVA, *tC3 = tC2 + nC2, *tC4 = tC3 + nC3;
+        float *tCM = h->tab, *tCA = tCM + nCM, *tVM = tCA + nCA, *tVA = tVM + nVM, *tC2 = tVA + nVA, *tC3 = tC2 + nC2, *tC4 = tC3 + nC3, *tREC = tC4 + nC4;
         const float *w = h->wdev;
         const WrnnPacked &o = h->off;
         HIP_TRY(h, wrnn_launch_frame_linear(1, mels_dev, (size_t)F * T, 0, 0, w + o.I_t + (size_t)1 * H, H, nullptr, tCM, (size_t)TP * H, TP, F, H, B, T, P, s));
@@ -434,16 +438,17 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + A, (size_t)T * R, R, T, w + o.r2_wih_t + (size_t)H * 3 * H, 3 * H, w + o.r2_bih, tC2, (size_t)T1 * 3 * H, T1, A, 3 * H, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 2 * A, (size_t)T * R, R, T, w + o.fc1_t + (size_t)H * FC, FC, w + o.fc1_b, tC3, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 3 * A, (size_t)T * R, R, T, w + o.fc2_t + (size_t)FC * FC, FC, w + o.fc2_b, tC4, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
+        HIP_TRY(h, wrnn_launch_pack_records(tCM, tCA, tVM, tVA, tREC, B, T, P, s));
         HIP_TRY(h, hipMemsetAsync(h->mail, 0, (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long), s));
         HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 64, s));
         HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work
         WrnnTeamArgs ta{};
         ta.w = w; ta.off = o; ta.d = d; ta.team_w = h->team_w; ta.team_fc3 = h->team_fc3; ta.wI0 = h->wI0; ta.u1 = h->u1;
-        ta.tabCM = tCM; ta.tabCA = tCA; ta.tabVM = tVM; ta.tabVA = tVA; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
+        ta.tabREC = tREC; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
         ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = 8; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
         ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced;
         ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
-        ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev;
+        ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;
         HIP_TRY(h, wrnn_launch_loop_team(ta, s));
     } else {
         return fail(h, WRNN_ERR_INVALID, "kernel %d not available", kernel);
@@ -464,6 +469,17 @@ int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out) {
     unsigned errw = 0;
     HIP_TRY(h, hipMemcpy(&errw, h->err_dev, sizeof(errw), hipMemcpyDeviceToHost));
     if (out) *out = h->last;
+    if (h->prof && h->last.kernel == WRNN_KERNEL_TEAM) {
+        unsigned long long pr[8 * 17];
+        HIP_TRY(h, hipMemcpy(pr, h->prof, sizeof(pr), hipMemcpyDeviceToHost));
+        const double n = (double)h->last.steps * ((h->last.rows + 7) / 8);
+        for (int wv = 0; wv < 8; ++wv) {
+            fprintf(stderr, "[wrnn prof] wg%d wave%d cycles/step:", wv < 4 ? 0 : 31, wv & 3);
+            double tot = 0;
+            for (int i = 0; i < 17; ++i) { fprintf(stderr, " %.0f", pr[wv * 17 + i] / n); tot += pr[wv * 17 + i] / n; }
+            fprintf(stderr, " | total %.0f\n", tot);
+        }
+    }
     if (errw) return fail(h, WRNN_ERR_TIMEOUT, "device-side bounded spin gave up (code %u)", errw);
     return WRNN_OK;
 }

@@ -36,6 +36,19 @@ __host__ __device__ inline float wrnn_uniform(uint64_t seed, uint64_t t, uint32_
     return u01_from_bits(bits);
 }
 
+// RAW sampling noise: the uniform behind q_k of (step t, row, class k).  One Philox block serves classes
+// (2j, 2j+1) for steps (2s, 2s+1): block counter (t>>1, row, k>>1), element ((t&1)<<1)|(k&1) -- a kernel that
+// owns a class pair evaluates the block every other step.
+__host__ __device__ inline Philox4 wrnn_raw_block(uint64_t seed, uint64_t t, uint32_t row, uint32_t k) {
+    const uint64_t th = t >> 1;
+    return philox4x32_10((uint32_t)th, (uint32_t)(th >> 32), row, k >> 1, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__host__ __device__ inline float wrnn_uniform_raw(uint64_t seed, uint64_t t, uint32_t row, uint32_t k) {
+    const Philox4 p = wrnn_raw_block(seed, t, row, k);
+    const uint32_t sel = (uint32_t)((t & 1u) << 1) | (k & 1u);
+    return u01_from_bits(sel == 0 ? p.x : sel == 1 ? p.y : sel == 2 ? p.z : p.w);
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // tanh via exp: tanh(x) = 1 - 2/(exp(2x)+1); accurate to ~2 ulp in fp32 for the GRU range
 __device__ __forceinline__ float tanh_f(float x) {

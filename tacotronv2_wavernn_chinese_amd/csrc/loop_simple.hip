@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(SIMPLE_THREADS) loop_simple_kernel(WrnnLoopArg
                 if (a.noise_mode == WRNN_NOISE_INJECTED) {
                     v -= logf(a.noise1[((size_t)t * a.n_rows + row) * NC + c]);
                 } else if (a.noise_mode == WRNN_NOISE_PHILOX) {
-                    const float u = wrnn_uniform(a.seed, (uint64_t)t, (uint32_t)row, (uint32_t)c);
+                    const float u = wrnn_uniform_raw(a.seed, (uint64_t)t, (uint32_t)row, (uint32_t)c);
                     v -= logf(-logf(u));
                 }
                 if (v > bv) { bv = v; bi = c; }

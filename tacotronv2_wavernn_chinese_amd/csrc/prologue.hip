@@ -223,3 +223,34 @@ hipError_t wrnn_launch_frame_linear(int mode, const float *src, size_t src_bstri
                            out_bstride, frames, K, N, T, P);
     return hipGetLastError();
 }
+
+// Team kernel conditioning records: REC[b][fi][j][28], fi in [0, T] (fi == T: zero conditioning, used for
+// fold padding), j = hidden unit.  One record holds everything phase A of unit j needs during frame fi:
+//   [0] CA[fi][j]   [1..3] VA[fi][r,z,n][j]   [4..8] CM[fi+dd][j], dd<5   [9+3dd+g] VM[fi+dd][g][j]   [24..27] pad
+// (28 floats = 112 B: a conflict-free ds_read_b128 stride).  The 5-frame windows overlap, i.e. the tables are
+// stored 5x redundantly in HBM so that the per-frame LDS refill is one straight 56 KB copy.
+__global__ void __launch_bounds__(256)
+pack_records_kernel(const float *__restrict__ CM, const float *__restrict__ CA, const float *__restrict__ VM,
+                    const float *__restrict__ VA, float *__restrict__ rec, int T, int P) {
+    const int fi = blockIdx.x, b = blockIdx.y;
+    const int TP = T + 2 * P, T1 = T + 1;
+    const float *cm = CM + (size_t)b * TP * 512, *ca = CA + (size_t)b * T1 * 512;
+    const float *vm = VM + (size_t)b * TP * 1536, *va = VA + (size_t)b * T1 * 1536;
+    float *out = rec + ((size_t)b * T1 + fi) * 512 * 28;
+    const bool live = fi < T;
+    for (int i = threadIdx.x; i < 512 * 28; i += blockDim.x) {
+        const int j = i / 28, f = i - j * 28;
+        float v = 0.0f;
+        if (f == 0) v = ca[(size_t)fi * 512 + j];
+        else if (f < 4) v = va[(size_t)fi * 1536 + (f - 1) * 512 + j];
+        else if (f < 9) { if (live) v = cm[(size_t)(fi + f - 4) * 512 + j]; }
+        else if (f < 24) { const int dd = (f - 9) / 3, g = (f - 9) - 3 * dd; if (live) v = vm[(size_t)(fi + dd) * 1536 + g * 512 + j]; }
+        out[i] = v;
+    }
+}
+
+hipError_t wrnn_launch_pack_records(const float *CM, const float *CA, const float *VM, const float *VA, float *rec, int B,
+                                    int T, int P, hipStream_t s) {
+    hipLaunchKernelGGL(pack_records_kernel, dim3(T + 1, B), dim3(256), 0, s, CM, CA, VM, VA, rec, T, P);
+    return hipGetLastError();
+}

@@ -82,6 +82,7 @@ struct wrnn_handle {
     size_t tab_cap = 0;
     unsigned long long *mail = nullptr;
     unsigned *ctl = nullptr;
+    unsigned long long *prof = nullptr;   // set when WRNN_TEAM_PROF=1 in the environment
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
     wrnn_timing last{};
@@ -125,11 +126,11 @@ struct WrnnTeamArgs {
     const float *team_fc3;    // [32 WGs][16384] LDS image of the fc3 slices
     const float *wI0;         // [H]   W_I[:,0]
     const float *u1;          // [3H]  W_ih1 . W_I[:,0]
-    // per-utterance conditioning tables pushed through the linear layers
-    const float *tabCM;       // (B, T+2P, H)   W_I[:,1:1+F] . melpad[f]
-    const float *tabCA;       // (B, T+1, H)    W_I[:,1+F:] . a1[i] + b_I         (entry T: zero conditioning)
-    const float *tabVM;       // (B, T+2P, 3H)  W_ih1 . CM[f]
-    const float *tabVA;       // (B, T+1, 3H)   W_ih1 . CA[i] + b_ih1
+    // per-utterance conditioning pushed through the linear layers it feeds:
+    //   CM (T+2P, H) = W_I[:,1:1+F] . melpad[f]     CA (T+1, H) = W_I[:,1+F:] . a1[i] + b_I (entry T: zeros in)
+    //   VM (T+2P,3H) = W_ih1 . CM[f]                VA (T+1,3H) = W_ih1 . CA[i] + b_ih1
+    // packed per frame and hidden unit, see pack_records_kernel (prologue.hip)
+    const float *tabREC;      // (B, T+1, H, 28)
     const float *tabC2;       // (B, T+1, 3H)   W_ih2[:,H:] . a2[i] + b_ih2
     const float *tabC3;       // (B, T+1, FC)   fc1.W[:,H:] . a3[i] + b1
     const float *tabC4;       // (B, T+1, FC)   fc2.W[:,FC:] . a4[i] + b2
@@ -150,6 +151,7 @@ struct WrnnTeamArgs {
     unsigned long long *mail;  // [n_teams][WRNN_TEAM_MAIL_GRANULES]
     unsigned *ctl;             // [16] per-XCD arrival counters
     unsigned *err;
+    unsigned long long *prof;  // [8][17] phase cycle counters (developer instrumentation) or null
 };
 
 // kernels / launchers (defined in the .hip files)
@@ -159,6 +161,8 @@ hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, cons
                                    int T, float *up, float *aux_up, hipStream_t s);
 hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
 hipError_t wrnn_launch_loop_team(const WrnnTeamArgs &a, hipStream_t s);
+hipError_t wrnn_launch_pack_records(const float *CM, const float *CA, const float *VM, const float *VA, float *rec, int B,
+                                    int T, int P, hipStream_t s);
 // out[b][f][n] = bias[n] + sum_k in(b,f,k) * Wt[k*ldw + n]; mode 0: row-major src (rows >= valid read as 0),
 // mode 1: src = mels (B,F,T) read as zero-padded frames melpad[f] = mel[:, f - P]
 hipError_t wrnn_launch_frame_linear(int mode, const float *src, size_t src_bstride, int ld, int valid, const float *Wt,

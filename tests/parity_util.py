@@ -57,5 +57,9 @@ def check_mol(got_samples, got_mix, ref, teacher_forced):
         ok[mism] = False
         ok[end:] = False
         err = np.abs(got_samples[ok, r] - ref['samples'][ok, r])
-        assert err.size == 0 or err.max() <= 1e-4, f'row {r}: max sample error {err.max():.3e}'
-        assert err.size == 0 or err.max() < MOL_LSB
+        # teacher-forced: every step starts from the oracle's own state -> fp32 round-off only.
+        # free-running: the fed-back value is continuous (no quantiser re-synchronises the two
+        # trajectories), so round-off differences accumulate over thousands of steps; they must stay
+        # well inside one 9-bit LSB.
+        tol = 2e-5 if teacher_forced else MOL_LSB / 4
+        assert err.size == 0 or err.max() <= tol, f'row {r}: max sample error {err.max():.3e} (tol {tol:.1e})'

@@ -31,3 +31,22 @@ def philox_uniform(seed: int, steps: int, rows: int, n: int) -> np.ndarray:
     out = _philox((c0, c1, c2, c3), (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
     bits = np.stack(out, axis=-1).reshape(steps, rows, -1)[:, :, :n]
     return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def philox_uniform_raw(seed: int, steps: int, rows: int, n: int) -> np.ndarray:
+    """(steps, rows, n) uniforms identical to wrnn_uniform_raw(seed, t, row, k):
+    block counter (t>>1, row, k>>1), element ((t&1)<<1)|(k&1)."""
+    th = (np.arange(steps, dtype=np.uint64) >> np.uint64(1))[:, None, None]
+    r = np.arange(rows, dtype=np.uint32)[None, :, None]
+    k2 = np.arange((n + 1) // 2, dtype=np.uint32)[None, None, :]
+    shape = (steps, rows, k2.shape[-1])
+    c0 = np.broadcast_to((th & np.uint64(0xFFFFFFFF)).astype(np.uint32), shape)
+    c1 = np.broadcast_to((th >> np.uint64(32)).astype(np.uint32), shape)
+    c2 = np.broadcast_to(r, shape)
+    c3 = np.broadcast_to(k2, shape)
+    x, y, z, w = _philox((c0, c1, c2, c3), (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    odd = (np.arange(steps) & 1).astype(bool)[:, None, None]
+    e0 = np.where(odd, z, x)   # class 2j
+    e1 = np.where(odd, w, y)   # class 2j + 1
+    bits = np.stack([e0, e1], axis=-1).reshape(steps, rows, -1)[:, :, :n]
+    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)

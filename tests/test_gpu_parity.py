@@ -11,6 +11,14 @@ from tests.parity_util import check_free_run_raw, check_mol, check_teacher_force
 pytestmark = pytest.mark.gpu
 
 KERNELS = ['team', 'simple']
+# The straightforward one-workgroup kernel runs ~1 ms/step: it is exercised on the B=3 case (3 rows in
+# parallel) and on the fold case only; the team kernel (the shipped path) runs every case.
+SIMPLE_CASES = {'raw_peaky_b3_t21', 'raw_peaky_fold_t30', 'mol_default_b2_t21'}
+
+
+def _skip_slow(name, kernel):
+    if kernel == 'simple' and name not in SIMPLE_CASES:
+        pytest.skip('simple kernel: covered on the multi-row cases only (1 ms/step)')
 
 
 def _model(fx, kernel='simple'):
@@ -42,7 +50,9 @@ def _oracle(fx, x_forced=None, want_logits=False):
 
 
 def _oracle_run(fx, x_forced=None, want_logits=False):
-    om = orc.OracleModel(fx['state_dict'], mode=fx['mode'], bits=int(fx['bits']))
+    # OpenMP/AVX2 build of the same C restatement (sums re-associated): the comparison rules already allow
+    # for summation-order differences, and the GPU box pays for every CPU second
+    om = orc.OracleModel(fx['state_dict'], mode=fx['mode'], bits=int(fx['bits']), fast=True)
     cm, ca = om.conditioning(fx['mels'])
     if fx['batched']:
         cm = om.fold(cm, int(fx['target']), int(fx['overlap']))
@@ -84,6 +94,7 @@ def test_conditioning_matches_reference(name):
 @pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('name', RAW_CASES)
 def test_raw_teacher_forced_every_step(name, kernel):
+    _skip_slow(name, kernel)
     fx = load_case(name)
     free = _oracle(fx)
     # the reference's own labels are the golden truth for the fed-back sequence
@@ -103,6 +114,7 @@ def test_raw_teacher_forced_every_step(name, kernel):
 @pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('name', RAW_CASES)
 def test_raw_free_running_matches_reference_labels(name, kernel):
+    _skip_slow(name, kernel)
     fx = load_case(name)
     ref = _oracle(fx)
     m = _model(fx, kernel)
@@ -119,6 +131,7 @@ def test_raw_free_running_matches_reference_labels(name, kernel):
 @pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('name', MOL_CASES)
 def test_mol_parity(name, kernel):
+    _skip_slow(name, kernel)
     fx = load_case(name)
     m = _model(fx, kernel)
     ref = _oracle(fx)
@@ -179,14 +192,14 @@ def test_philox_sampling_is_distributionally_correct():
     """Own-RNG production mode: the kernel's draws are reproduced on the host (same Philox, numpy) and
     injected into the oracle -> same labels (near-tie rule)."""
     from tacotronv2_wavernn_chinese_amd import _cabi
-    from tests.philox_ref import philox_uniform
+    from tests.philox_ref import philox_uniform_raw
     fx = load_case('raw_peaky_b1_t24')
     m = _model(fx)
     seed = 0x1234ABCD5678
     res = m.generate_raw(fx['mels'], False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=seed)
     got = res['labels'].cpu().numpy().T
     L = got.shape[0]
-    u = philox_uniform(seed, L, 1, 1024)
+    u = philox_uniform_raw(seed, L, 1, 1024)
     q = (-np.log(u.astype(np.float64))).astype(np.float32)
     om = orc.OracleModel(fx['state_dict'])
     cm, ca = om.conditioning(fx['mels'])

@@ -22,11 +22,13 @@ def model(mode='RAW', variant='peaky'):
 def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 41
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    for mode in ('RAW', 'MOL'):
+    modes = ('RAW',) if len(sys.argv) > 3 and sys.argv[3] == 'raw' else ('RAW', 'MOL')
+    kernels = (('team', _cabi.KERNEL_TEAM),) if len(sys.argv) > 4 and sys.argv[4] == 'team' else (('simple', _cabi.KERNEL_SIMPLE), ('team', _cabi.KERNEL_TEAM))
+    for mode in modes:
         m = model(mode)
         mels = make_mels(3, B, T)
         out = {}
-        for name, k in (('simple', _cabi.KERNEL_SIMPLE), ('team', _cabi.KERNEL_TEAM)):
+        for name, k in kernels:
             try:
                 t0 = time.time()
                 r = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=77, kernel=k)
