@@ -71,7 +71,7 @@ def main() -> int:
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--frames', type=int, default=T_FRAMES)
-    ap.add_argument('--kernel', default='auto', choices=['auto', 'team', 'simple'])
+    ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'team', 'simple'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -100,7 +100,7 @@ def main() -> int:
     model.verbose = False
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model.to(dev)
-    model.kernel = {'auto': _cabi.KERNEL_AUTO, 'team': _cabi.KERNEL_TEAM, 'simple': _cabi.KERNEL_SIMPLE}[args.kernel]
+    model.kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'team': _cabi.KERNEL_TEAM, 'simple': _cabi.KERNEL_SIMPLE}[args.kernel]
     T = args.frames
     mels = torch.from_numpy(make_mels(1000 + rank, 1, T)).to(dev)   # resident in HBM before timing
     nat = model.native()
@@ -152,7 +152,7 @@ def main() -> int:
             'config': {'workload': f'BASELINE configs[1]: 1 utterance per GPU per step, B=1, mel 80x{T} '
                                    f'({L} loop steps = {audio_s:.3f} s audio), RAW 10-bit, hop 275, prologue+loop, '
                                    'Philox sampling noise, seeded synthetic weights (fc3 x128)',
-                       'kernel': {1: 'simple', 2: 'team'}.get(kernel_ran, str(kernel_ran)),
+                       'kernel': {1: 'simple', 2: 'team', 3: 'team2'}.get(kernel_ran, str(kernel_ran)),
                        'real_time_factor': round((dt / args.steps) / audio_s, 4),
                        'times_real_time': round(audio_s / (dt / args.steps), 2),
                        'prologue_ms': round(float(np.mean(pro_ms)), 3), 'loop_kernel_ms': round(k_ms, 3),

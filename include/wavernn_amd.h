@@ -42,7 +42,8 @@ extern "C" {
 /* which device implementation runs the per-sample loop */
 #define WRNN_KERNEL_AUTO 0
 #define WRNN_KERNEL_SIMPLE 1 /* one workgroup per row, weights streamed from L2/HBM */
-#define WRNN_KERNEL_TEAM 2   /* one XCD-resident team per row group, weights on chip */
+#define WRNN_KERNEL_TEAM 2   /* one XCD-resident team per row, weights on chip, 4 waves per workgroup */
+#define WRNN_KERNEL_TEAM2 3  /* same team, 8 waves per workgroup specialised into critical / shadow roles */
 
 /* tensor dtypes accepted by wrnn_load_weights */
 #define WRNN_DTYPE_F32 0

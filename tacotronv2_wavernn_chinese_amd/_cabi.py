@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libwavernn_amd.so')
 
 MODE_RAW, MODE_MOL = 0, 1
 NOISE_PHILOX, NOISE_INJECTED, NOISE_ARGMAX = 0, 1, 2
-KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM = 0, 1, 2
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM, KERNEL_TEAM2 = 0, 1, 2, 3
 DTYPE_F32, DTYPE_I64 = 0, 1
 ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN_ERR_STATE',
              -4: 'WRNN_ERR_MISSING_KEY', -5: 'WRNN_ERR_TIMEOUT'}

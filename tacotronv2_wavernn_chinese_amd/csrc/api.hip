@@ -122,6 +122,7 @@ void wrnn_destroy(wrnn_handle *h) {
     if (h->wI0) (void)hipFree(h->wI0);
     if (h->u1) (void)hipFree(h->u1);
     if (h->tab) (void)hipFree(h->tab);
+    if (h->cond) (void)hipFree(h->cond);
     if (h->mail) (void)hipFree(h->mail);
     if (h->ctl) (void)hipFree(h->ctl);
     for (int i = 0; i < 3; ++i)
@@ -410,10 +411,15 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     a.noise_mode = opts->noise_mode; a.seed = opts->seed; a.noise1 = opts->noise1_dev; a.noise2 = opts->noise2_dev;
     a.x_forced = opts->x_forced_dev; a.logits_out = opts->logits_out_dev; a.labels_out = labels_out_dev;
     a.samples_out = samples_out_dev; a.err = h->err_dev;
-    int kernel = opts->kernel == WRNN_KERNEL_AUTO ? WRNN_KERNEL_TEAM : opts->kernel;
+    int kernel = opts->kernel;
+    if (kernel == WRNN_KERNEL_AUTO) {
+        // the wave-specialised kernel streams 8 KB of conditioning per step from HBM; keep that stream under the cap
+        const size_t cond_bytes = (size_t)rows * (size_t)steps * d.H * 4 * sizeof(float);
+        kernel = cond_bytes <= ((size_t)96 << 30) ? WRNN_KERNEL_TEAM2 : WRNN_KERNEL_TEAM;
+    }
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));
-    } else if (kernel == WRNN_KERNEL_TEAM) {
+    } else if (kernel == WRNN_KERNEL_TEAM || kernel == WRNN_KERNEL_TEAM2) {
         if (d.ND != 5 || d.HOP > 275) return fail(h, WRNN_ERR_INVALID, "team kernel is built for pad=2 (5-frame upsampling support), hop <= 275");
         // conditioning pushed through the linear layers it feeds (once per call)
         const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, P = d.P;
@@ -424,6 +430,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         const size_t need = nCM + nCA + nVM + nVA + nC2 + nC3 + nC4 + nREC;
         if (need > h->tab_cap) {
             if (h->tab) (void)hipFree(h->tab);
+    if (h->cond) (void)hipFree(h->cond);
             h->tab = nullptr; h->tab_cap = 0;
             HIP_TRY(h, hipMalloc(&h->tab, need * sizeof(float)));
             h->tab_cap = need;
@@ -439,17 +446,32 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 2 * A, (size_t)T * R, R, T, w + o.fc1_t + (size_t)H * FC, FC, w + o.fc1_b, tC3, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 3 * A, (size_t)T * R, R, T, w + o.fc2_t + (size_t)FC * FC, FC, w + o.fc2_b, tC4, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         HIP_TRY(h, wrnn_launch_pack_records(tCM, tCA, tVM, tVA, tREC, B, T, P, s));
+        float *tCOND = nullptr;
+        if (kernel == WRNN_KERNEL_TEAM2) {
+            const size_t nCOND = (size_t)rows * (size_t)steps * H * 4;
+            if (nCOND * sizeof(float) > ((size_t)96 << 30))
+                return fail(h, WRNN_ERR_INVALID, "conditioning stream of %zu GB exceeds the 96 GB cap: split the batch", (nCOND * 4) >> 30);
+            if (nCOND > h->cond_cap) {
+                if (h->cond) (void)hipFree(h->cond);
+                h->cond = nullptr; h->cond_cap = 0;
+                HIP_TRY(h, hipMalloc(&h->cond, nCOND * sizeof(float)));
+                h->cond_cap = nCOND;
+            }
+            tCOND = h->cond;
+            HIP_TRY(h, wrnn_launch_cond_stream(tREC, w + o.ktab, h->rows_dev, tCOND, rows, T, d.HOP, a.total_len, steps, s));
+        }
         HIP_TRY(h, hipMemsetAsync(h->mail, 0, (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long), s));
         HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 64, s));
         HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work
         WrnnTeamArgs ta{};
         ta.w = w; ta.off = o; ta.d = d; ta.team_w = h->team_w; ta.team_fc3 = h->team_fc3; ta.wI0 = h->wI0; ta.u1 = h->u1;
-        ta.tabREC = tREC; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
+        ta.tabREC = tREC; ta.tabCOND = tCOND; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
         ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = 8; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
         ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced;
         ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
         ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;
-        HIP_TRY(h, wrnn_launch_loop_team(ta, s));
+        if (kernel == WRNN_KERNEL_TEAM2) HIP_TRY(h, wrnn_launch_loop_team2(ta, s));
+        else HIP_TRY(h, wrnn_launch_loop_team(ta, s));
     } else {
         return fail(h, WRNN_ERR_INVALID, "kernel %d not available", kernel);
     }

@@ -55,36 +55,8 @@ __device__ __forceinline__ void st_granule(u64 *base, unsigned idx, unsigned tag
     asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
 
-// Poll N granules p[0], p[stride], ... until all carry `tag`; all loads of one
-// round are in flight together.  (g >> SHIFT) is compared with tag.
-template <int N, int SHIFT>
-__device__ __forceinline__ void poll_n(const u64 *base, unsigned idx, unsigned stride, unsigned tag, u64 (&g)[N], bool &dead,
-                                       unsigned *err, unsigned code) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) g[i] = 0;
-    if (dead) return;
-    unsigned spins = 0;
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const unsigned off = (idx + (unsigned)i * stride) * 8u;
-            asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=&v"(g[i]) : "v"(off), "s"(base) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            asm volatile("" : "+v"(g[i]));
-            ok = ok && ((unsigned)(g[i] >> SHIFT) == tag);
-        }
-        if (ok) return;
-        if (++spins > TEAM_SPIN_MAX) { dead = true; atomicExch(err, code); return; }
-    }
-}
-
-// Early, compiler-visible first look at N granules (relaxed agent-scope load = global_load ... sc1).
-// Issued in the middle of shadow work so that its L2 round trip (~600 cycles) is hidden; only lanes
-// whose granules had not landed yet fall back to the poll loop.
+// First look at N granules (relaxed agent-scope load = global_load ... sc1, compiler-visible so that it can be
+// issued in the middle of shadow work and waited for at first use: its ~600-cycle L2 round trip is hidden).
 template <int N>
 __device__ __forceinline__ void peek_n(const u64 *base, unsigned idx, unsigned stride, u64 (&g)[N]) {
 #pragma unroll
@@ -96,6 +68,18 @@ __device__ __forceinline__ bool tags_ok(const u64 (&g)[N], unsigned tag) {
 #pragma unroll
     for (int i = 0; i < N; ++i) ok = ok && ((unsigned)(g[i] >> SHIFT) == tag);
     return ok;
+}
+// Complete an exchange: re-read until every lane of the wave holds granules tagged `tag`.  The loop is
+// WAVE-uniform (no exec-mask bookkeeping): lanes that already hold their data simply re-read it.  Bounded:
+// on a timeout the (wave-uniform) dead flag is raised, the error word set, and every later poll is skipped.
+template <int N, int SHIFT>
+__device__ __forceinline__ void finish_n(const u64 *base, unsigned idx, unsigned stride, unsigned tag, u64 (&g)[N], bool &dead,
+                                         unsigned *err, unsigned code) {
+    unsigned spins = 0;
+    while (!dead && !__all(tags_ok<N, SHIFT>(g, tag))) {
+        if (++spins > TEAM_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+        peek_n<N>(base, idx, stride, g);
+    }
 }
 
 template <int CTRL>
@@ -478,7 +462,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
             // ---- exchange 1: x3 = x + h2 for all units; h2' = x3 - x2 ---------------------
             {
                 u64 (&gq)[2] = gx;
-                if (!tags_ok<2, 32>(gq, epoch)) poll_n<2, 32>(mX3, par * 512 + tid, 256, epoch, gq, dead, a.err, 11u);
+                finish_n<2, 32>(mX3, par * 512 + tid, 256, epoch, gq, dead, a.err, 11u);
                 const float x3_0 = __uint_as_float((unsigned)gq[0]), x3_1 = __uint_as_float((unsigned)gq[1]);
                 xb[XB_X3 * 512 + pj0] = x3_0; xb[XB_X3 * 512 + pj1] = x3_1;
                 xb[XB_H2 * 512 + pj0] = x3_0 - x2_0; xb[XB_H2 * 512 + pj1] = x3_1 - x2_1;
@@ -507,7 +491,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
             // ---- exchange 2: fc1 outputs ------------------------------------------------------
             {
                 u64 (&gq)[2] = gf;
-                if (!tags_ok<2, 32>(gq, epoch)) poll_n<2, 32>(mF1, par * 512 + tid, 256, epoch, gq, dead, a.err, 12u);
+                finish_n<2, 32>(mF1, par * 512 + tid, 256, epoch, gq, dead, a.err, 12u);
                 xb[XB_F1 * 512 + pj0] = __uint_as_float((unsigned)gq[0]);
                 xb[XB_F1 * 512 + pj1] = __uint_as_float((unsigned)gq[1]);
             }
@@ -529,7 +513,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
             {
                 u64 gq[2];
                 peek_n<2>(mF2, par * 512 + tid, 256, gq);
-                if (!tags_ok<2, 32>(gq, epoch)) poll_n<2, 32>(mF2, par * 512 + tid, 256, epoch, gq, dead, a.err, 13u);
+                finish_n<2, 32>(mF2, par * 512 + tid, 256, epoch, gq, dead, a.err, 13u);
                 xb[XB_F2 * 512 + pj0] = __uint_as_float((unsigned)gq[0]);
                 xb[XB_F2 * 512 + pj1] = __uint_as_float((unsigned)gq[1]);
             }
@@ -583,7 +567,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
                 PROF_MARK(0);
                 // ---- exchange 4 (wave 0) + gh1 collection (waves 1-3) ------------------------
                 if (wave == 0) {
-                    if (!tags_ok<8, 42>(gq, epoch & 0x3fffffu)) poll_n<8, 42>(mPR, par * 512 + lane * 8, 1, epoch & 0x3fffffu, gq, dead, a.err, 14u);
+                    finish_n<8, 42>(mPR, par * 512 + lane * 8, 1, epoch & 0x3fffffu, gq, dead, a.err, 14u);
                     float best = -INFINITY; int besti = 0;
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
@@ -599,7 +583,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
                 } else {
                     // gh1 for the next step (published during phase B of this step): 192 threads x 8
                     const int base = ghbase;
-                    if (!tags_ok<8, 32>(gq, epoch)) poll_n<8, 32>(mGH, par * 1536 + base, 192, epoch, gq, dead, a.err, 15u);
+                    finish_n<8, 32>(mGH, par * 1536 + base, 192, epoch, gq, dead, a.err, 15u);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) gh1s[base + m * 192] = __uint_as_float((unsigned)gq[m]);
                 }
@@ -625,7 +609,12 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
                     float mylg = 0.0f;
                     if (lane < NC) {
                         u64 gq[1];
-                        poll_n<1, 32>(mPR, par * 512 + lane, 1, epoch, gq, dead, a.err, 16u);
+                        peek_n<1>(mPR, par * 512 + lane, 1, gq);
+                        unsigned spins = 0;
+                        while (!dead && (unsigned)(gq[0] >> 32) != epoch) {
+                            if (++spins > TEAM_SPIN_MAX) { dead = true; atomicExch(a.err, 16u); break; }
+                            peek_n<1>(mPR, par * 512 + lane, 1, gq);
+                        }
                         mylg = __uint_as_float((unsigned)gq[0]);
                     }
                     float v = -INFINITY;
@@ -649,7 +638,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
                 } else {
                     u64 gq[8];
                     const int base = tid - 64;
-                    poll_n<8, 32>(mGH, par * 1536 + base, 192, epoch, gq, dead, a.err, 15u);
+                    peek_n<8>(mGH, par * 1536 + base, 192, gq);
+                    finish_n<8, 32>(mGH, par * 1536 + base, 192, epoch, gq, dead, a.err, 15u);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) gh1s[base + m * 192] = __uint_as_float((unsigned)gq[m]);
                 }
@@ -663,7 +653,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
             xprev = a.x_forced ? xforce_now : x_new;   // (:228, :237)
             PROF_MARK(16);
             if ((t & 63) == 63) {   // bounded-spin bail-out, checked workgroup-wide every 64 steps
-                if (dead) misc_i[10] = 1;
+                if (dead && lane == 0) misc_i[10] = 1;
                 __syncthreads();
                 if (misc_i[10]) return;
             }

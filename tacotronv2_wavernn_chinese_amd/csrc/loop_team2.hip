@@ -1,0 +1,566 @@
+// WRNN_KERNEL_TEAM2: the per-sample loop (fatchord_version.py:194-241) with WAVE SPECIALISATION.
+//
+// Same team structure and exchange protocol as loop_team.hip (one team = the 32 workgroups of one XCD,
+// fp32 weights resident on chip, 8-byte {tag,value} granules through the XCD's L2, 4 exchanges on the critical
+// path + 1 off it, 5 workgroup barriers per step).  What changes is who does what inside a workgroup.
+//
+// Measured on loop_team.hip (profiles/): with one wave per SIMD the kernel is bound by single-wave
+// instruction issue (~1 instruction / 4 cycles): ~2100 instructions per step, of which only ~35 % belong to the
+// serial chain x -> GRU1 -> GRU2 -> fc1 -> fc2 -> fc3 -> sample; the rest is work that never waits on x_t
+// (W_hh1.h1, W_hh2.h2, conditioning and noise of the next step, the gh1 gather) plus 256 v_accvgpr_read for
+// weights parked in AGPRs.  So: 8 waves per workgroup, two per SIMD, and the two waves of a SIMD get different jobs:
+//   waves 0-3 "C" (critical): W_ih2 (96) + fc1 (32) + fc2 (32) weights in VGPRs, fc3 slice in LDS;
+//                             phases B, C, D, E and the race reduction (wave 0);
+//   waves 4-7 "S" (shadow):   W_hh1 (96) + W_hh2 (96) weights in VGPRs; gh1, gh2, next-step conditioning,
+//                             sampling noise, per-frame record refill, gh1 gather.
+// All 512 threads share phase A (unit j = tid) and the exchange polls (granule tid).  No AGPR parking is needed:
+// 2 waves/SIMD x 256 registers hold 192 (S) / 160 (C) weights + the working set.  S hands its results to C through
+// small LDS slots between the same 5 barriers.
+//
+// Thread map inside a role (wl = wave & 3, lane l: quarter r4 = l>>4, q = l&15): quarter-wave (wl, r4) owns hidden
+// unit / fc row u = 16 g + 4 wl + r4 and columns 32q..32q+31 of every row it owns.
+#include "device_util.h"
+#include "wrnn_internal.h"
+
+#define T2_WGS 32
+#define T2_THREADS 512
+#define T2_SPIN_MAX 300000u
+
+typedef unsigned long long u64;
+
+namespace {
+
+__device__ __forceinline__ unsigned xcc_id2() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+
+// 8-byte granule {tag (hi), payload (lo)}: plain store (-> the XCD's L2), sc1 load (bypasses L1).  Same-XCD only.
+__device__ __forceinline__ void st_granule(u64 *base, unsigned idx, unsigned tag, unsigned payload) {
+    const u64 v = ((u64)tag << 32) | payload;
+    const unsigned off = idx * 8u;
+    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void peek_n(const u64 *base, unsigned idx, unsigned stride, u64 (&g)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = __hip_atomic_load(base + idx + (unsigned)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int N, int SHIFT>
+__device__ __forceinline__ bool tags_ok(const u64 (&g)[N], unsigned tag) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ok = ok && ((unsigned)(g[i] >> SHIFT) == tag);
+    return ok;
+}
+// wave-uniform completion loop (see loop_team.hip); bounded
+template <int N, int SHIFT>
+__device__ __forceinline__ void finish_n(const u64 *base, unsigned idx, unsigned stride, unsigned tag, u64 (&g)[N], bool &dead,
+                                         unsigned *err, unsigned code) {
+    unsigned spins = 0;
+    while (!dead && !__all(tags_ok<N, SHIFT>(g, tag))) {
+        if (++spins > T2_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+        peek_n<N>(base, idx, stride, g);
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum(float v) {   // sum over the 16 lanes of a DPP row, result in every lane
+    v += dpp_get<0xB1>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x141>(v);
+    v += dpp_get<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {   // max over 64 lanes, valid in lane 63
+#define WMAX_STEP(CTRL, RM) \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false)))
+    WMAX_STEP(0xB1, 0xf); WMAX_STEP(0x4E, 0xf); WMAX_STEP(0x141, 0xf); WMAX_STEP(0x140, 0xf);
+    WMAX_STEP(0x142, 0xa); WMAX_STEP(0x143, 0xc);
+#undef WMAX_STEP
+    return v;
+}
+
+// activation vectors in LDS: element j -> plane p=(j>>2)&7, slot q=j>>5 (8 conflict-free ds_read_b128 per lane)
+__device__ __forceinline__ int perm(int j) { return ((j >> 2) & 7) * 64 + (j >> 5) * 4 + (j & 3); }
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// three rows (GRU gates) x the lane's 32-float chunk, weights w[0..95] in VGPRs; the chunk is consumed in two
+// halves of 16 floats to keep the live register set small
+__device__ __forceinline__ void dot32x3(const float *w, const float *vec, int q, float &o0, float &o1, float &o2) {
+    const float4 *p = (const float4 *)vec + q;
+    f2 a = mk2(0.f, 0.f), b = mk2(0.f, 0.f), c = mk2(0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = p[(4 * h + k) * 16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kk = 4 * h + k;
+            const f2 xl = mk2(x[k].x, x[k].y), xh = mk2(x[k].z, x[k].w);
+            a = pkfma(mk2(w[4 * kk + 0], w[4 * kk + 1]), xl, a);
+            b = pkfma(mk2(w[32 + 4 * kk + 0], w[32 + 4 * kk + 1]), xl, b);
+            c = pkfma(mk2(w[64 + 4 * kk + 0], w[64 + 4 * kk + 1]), xl, c);
+            a = pkfma(mk2(w[4 * kk + 2], w[4 * kk + 3]), xh, a);
+            b = pkfma(mk2(w[32 + 4 * kk + 2], w[32 + 4 * kk + 3]), xh, b);
+            c = pkfma(mk2(w[64 + 4 * kk + 2], w[64 + 4 * kk + 3]), xh, c);
+        }
+    }
+    o0 = a.x + a.y; o1 = b.x + b.y; o2 = c.x + c.y;
+}
+// W_hh2 on the S waves: gate rows r, z from VGPRs w[0..63], gate row n from this thread's LDS slots
+__device__ __forceinline__ void dot32x3_mixed(const float *w, const float4 *wl_, const float *vec, int q, float &o0, float &o1, float &o2) {
+    const float4 *p = (const float4 *)vec + q;
+    f2 a = mk2(0.f, 0.f), b = mk2(0.f, 0.f), c = mk2(0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 x[4], wn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[k] = p[(4 * h + k) * 16]; wn[k] = wl_[(4 * h + k) * 256]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kk = 4 * h + k;
+            const f2 xl = mk2(x[k].x, x[k].y), xh = mk2(x[k].z, x[k].w);
+            a = pkfma(mk2(w[4 * kk + 0], w[4 * kk + 1]), xl, a);
+            b = pkfma(mk2(w[32 + 4 * kk + 0], w[32 + 4 * kk + 1]), xl, b);
+            c = pkfma(mk2(wn[k].x, wn[k].y), xl, c);
+            a = pkfma(mk2(w[4 * kk + 2], w[4 * kk + 3]), xh, a);
+            b = pkfma(mk2(w[32 + 4 * kk + 2], w[32 + 4 * kk + 3]), xh, b);
+            c = pkfma(mk2(wn[k].z, wn[k].w), xh, c);
+        }
+    }
+    o0 = a.x + a.y; o1 = b.x + b.y; o2 = c.x + c.y;
+}
+__device__ __forceinline__ float dot32(const float *w, const float *vec, int q) {
+    const float4 *p = (const float4 *)vec + q;
+    f2 s0 = mk2(0.f, 0.f), s1 = mk2(0.f, 0.f);
+    float4 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = p[k * 16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s0 = pkfma(mk2(w[4 * k + 0], w[4 * k + 1]), mk2(x[k].x, x[k].y), s0);
+        s1 = pkfma(mk2(w[4 * k + 2], w[4 * k + 3]), mk2(x[k].z, x[k].w), s1);
+    }
+    return (s0.x + s0.y) + (s1.x + s1.y);
+}
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+
+// ---- LDS carve-up (floats); per-thread-base + constant families first (16-bit DS offsets) ---------------
+constexpr int L_COND = 0;                      // [512][4]  {cI, v_r, v_z, v_n} of the coming step (HBM stream -> everyone)
+constexpr int L_CSTA = L_COND + 512 * 4;       // [512][4]  {W_I[:,0], u_r, u_z, u_n}
+constexpr int L_GH1 = L_CSTA + 512 * 4;        // [3][512]  W_hh1.h1 + b_hh1 gathered from the team
+constexpr int L_CSTQ = L_GH1 + 1536;           // [16 quarters][16] b_hh1 rzn | b_hh2 rzn | b3 x2 | c2 rzn | c3 | c4
+constexpr int L_HAND = L_CSTQ + 256;           // [16 quarters][8]  S -> C: gh2 rzn | . | noise[2 parities][2]
+constexpr int L_MISC = L_HAND + 128;           // scratch words
+constexpr int L_XB = L_MISC + 64;              // 6 activation vectors x 512 (plane order)
+constexpr int XB_H1 = 0, XB_X2 = 1, XB_X3 = 2, XB_H2 = 3, XB_F1 = 4, XB_F2 = 5;
+constexpr int L_SW = L_XB + 6 * 512;           // [8 planes][256 S-threads][4]: the n-gate row of W_hh2 (32 weights / S thread)
+constexpr int L_FC3 = L_SW + 8 * 256 * 4;      // [4 C-waves][2 rows][8 planes][64 lanes][4]
+constexpr int L_TOTAL = L_FC3 + 16384;
+static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
+constexpr int M_XF = 9, M_K = 8, M_DEAD = 10;  // misc slots: fed-back sample, label, bail-out flag
+
+constexpr unsigned G_X3 = 0, G_F1 = 1024, G_F2 = 2048, G_PR = 3072, G_GH = 4096;  // mailbox regions (granules)
+
+}  // namespace
+
+template <int MODE>
+__global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = (float *)smem;
+    float *xb = lds + L_XB;
+    float *gh1s = lds + L_GH1;
+    int *misc_i = (int *)(lds + L_MISC);
+    float *misc_f = lds + L_MISC;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool isC = wave < 4;
+    const int wl = wave & 3;
+    const int r4 = lane >> 4, q = lane & 15;
+    const WrnnDims d = a.d;
+    const int NC = d.NC, HOP = d.HOP, T = a.T;
+    const float4 *swl = (const float4 *)(lds + L_SW) + (tid - 256);   // S threads only
+
+    // ---- team formation: by the XCD this workgroup actually runs on ------------
+    if (tid == 0) {
+        const unsigned x = xcc_id2();
+        misc_i[M_DEAD] = 0;
+        misc_i[0] = (int)x;
+        misc_i[1] = (int)atomicAdd(&a.ctl[x], 1u);
+    }
+    __syncthreads();
+    const int team = __builtin_amdgcn_readfirstlane(misc_i[0]);
+    const int g = __builtin_amdgcn_readfirstlane(misc_i[1]);
+    __syncthreads();
+    if (g >= T2_WGS || team >= a.n_teams || team >= a.n_rows) return;
+    u64 *mail = a.mail + (size_t)team * WRNN_TEAM_MAIL_GRANULES;
+
+    const int unit = 16 * g + 4 * wl + r4;          // hidden unit / fc1 / fc2 row of this quarter-wave
+    const int qslot = wl * 4 + r4;
+    const int c3row0 = 32 * g + 8 * wl + 2 * r4;    // first of the two fc3 rows of this C quarter-wave (even)
+    const bool has_fc3 = c3row0 < NC;
+
+    // ---- resident weights: team_w rows per (wl, lane): W_hh1 [0,96) | W_ih2 [96,192) | W_hh2 [192,288) | fc2 [288,320) | fc1 [320,352)
+    float wv[160];
+    {
+        const float *src = a.team_w + (size_t)g * WRNN_TEAM_NWREG * WRNN_TEAM_THREADS + (wl * 64 + lane);
+        if (isC) {
+#pragma unroll
+            for (int i = 0; i < 96; ++i) wv[i] = src[(size_t)(96 + i) * WRNN_TEAM_THREADS];     // W_ih2
+#pragma unroll
+            for (int i = 0; i < 64; ++i) wv[96 + i] = src[(size_t)(288 + i) * WRNN_TEAM_THREADS];  // fc2 | fc1
+        } else {
+#pragma unroll
+            for (int i = 0; i < 96; ++i) wv[i] = src[(size_t)i * WRNN_TEAM_THREADS];            // W_hh1
+#pragma unroll
+            for (int i = 0; i < 64; ++i) wv[96 + i] = src[(size_t)(192 + i) * WRNN_TEAM_THREADS];  // W_hh2 gates r, z
+#pragma unroll
+            for (int k = 0; k < 8; ++k)                                                          // W_hh2 gate n -> LDS planes
+                ((float4 *)(lds + L_SW))[k * 256 + (tid - 256)] =
+                    make_float4(src[(size_t)(256 + 4 * k) * WRNN_TEAM_THREADS], src[(size_t)(257 + 4 * k) * WRNN_TEAM_THREADS],
+                                src[(size_t)(258 + 4 * k) * WRNN_TEAM_THREADS], src[(size_t)(259 + 4 * k) * WRNN_TEAM_THREADS]);
+        }
+        const float4 *f3 = (const float4 *)(a.team_fc3 + (size_t)g * 16384);
+        float4 *dst = (float4 *)(lds + L_FC3);
+        for (int i = tid; i < 4096; i += T2_THREADS) dst[i] = f3[i];
+        // per-unit phase-A constants, unit j = tid
+        ((float4 *)(lds + L_CSTA))[tid] = make_float4(a.wI0[tid], a.u1[tid], a.u1[512 + tid], a.u1[1024 + tid]);
+        if (!isC && q == 0) {
+            float *cq = lds + L_CSTQ + qslot * 16;
+            cq[0] = a.w[a.off.r1_bhh + unit]; cq[1] = a.w[a.off.r1_bhh + 512 + unit]; cq[2] = a.w[a.off.r1_bhh + 1024 + unit];
+            cq[3] = a.w[a.off.r2_bhh + unit]; cq[4] = a.w[a.off.r2_bhh + 512 + unit]; cq[5] = a.w[a.off.r2_bhh + 1024 + unit];
+            cq[6] = has_fc3 ? a.w[a.off.fc3_b + c3row0] : 0.0f;
+            cq[7] = (c3row0 + 1 < NC) ? a.w[a.off.fc3_b + c3row0 + 1] : 0.0f;
+        }
+    }
+    __syncthreads();
+    float *cstQ = lds + L_CSTQ + qslot * 16;
+    float *hand = lds + L_HAND + qslot * 8;
+    const int pj = perm(tid), pu = perm(unit);
+    const int sidx = tid - 256;   // S threads: 0..255, prepare units sidx and sidx + 256
+
+    bool dead = false;
+    unsigned epoch = 0;
+
+    for (int row = team; row < a.n_rows; row += a.n_teams) {
+        const WrnnRow rw = a.rows[row];
+        const float4 *CONDg = (const float4 *)a.tabCOND + (size_t)row * a.steps * 512;
+        const float *C2g = a.tabC2 + (size_t)rw.utt * (T + 1) * 1536;
+        const float *C3g = a.tabC3 + (size_t)rw.utt * (T + 1) * 512;
+        const float *C4g = a.tabC4 + (size_t)rw.utt * (T + 1) * 512;
+
+        // h1 = h2 = 0, x = 0  (:194-196)  => gh1 = b_hh1, gh2 = b_hh2
+        float h1_j = 0.0f;
+        xb[XB_H2 * 512 + pj] = 0.0f;
+        for (int i = tid; i < 1536; i += T2_THREADS) gh1s[i] = a.w[a.off.r1_bhh + i];
+        if (tid == 0) misc_f[M_XF] = 0.0f;
+        // frame of the step being prepared, tracked incrementally by the S waves (for the per-frame C constants)
+        int nfi = (int)(rw.start / HOP), nph = (int)(rw.start - (int64_t)nfi * HOP);
+        int cst_frame = -1000000;   // frame whose c2/c3/c4 are in the C constants
+        int pend_frame = -1;        // frame whose constants must be written in the next B4-B5 window
+        float nzn0 = 0.f, nzn1 = 0.f;
+        float4 cnext0 = make_float4(0.f, 0.f, 0.f, 0.f), cnext1 = cnext0;   // conditioning prefetched two steps ahead
+
+        // S: everything of step ts that does not depend on x_{ts-1}: its conditioning (prefetched from the HBM
+        // stream one call earlier) -> L_COND for units sidx / sidx+256, prefetch of step ts+1, the frame bookkeeping,
+        // and the sampling noise of the paired C quarter -> hand[4 + 2*parity(ts)...]
+        auto s_prepare = [&](int64_t ts, unsigned ep_of_ts) {
+            const bool live = nfi < T;                  // fold padding 'after' = zero rows (:327-330)
+            const int fi = live ? nfi : T;              // T = the all-zero conditioning entry
+            if (++nph == HOP) { nph = 0; ++nfi; }
+            pend_frame = fi;
+            ((float4 *)(lds + L_COND))[sidx] = cnext0;
+            ((float4 *)(lds + L_COND))[sidx + 256] = cnext1;
+            if (ts + 1 < a.steps) {
+                cnext0 = CONDg[(size_t)(ts + 1) * 512 + sidx];
+                cnext1 = CONDg[(size_t)(ts + 1) * 512 + sidx + 256];
+            }
+            if (MODE == WRNN_MODE_RAW && has_fc3) {
+                float nz0 = 0.f, nz1 = 0.f;
+                if (a.noise_mode == WRNN_NOISE_INJECTED) {
+                    const float *qp = a.noise1 + ((size_t)ts * a.n_rows + row) * NC + c3row0;
+                    nz0 = -logf(qp[0]); nz1 = -logf(qp[1]);
+                } else if (a.noise_mode == WRNN_NOISE_PHILOX) {
+                    // one Philox block = classes (c3row0, c3row0+1) x steps (2s, 2s+1): evaluated on even steps
+                    if ((ts & 1) == 0) {
+                        const Philox4 pz = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)c3row0);
+                        nz0 = -__logf(-__logf(u01_from_bits(pz.x)));
+                        nz1 = -__logf(-__logf(u01_from_bits(pz.y)));
+                        nzn0 = -__logf(-__logf(u01_from_bits(pz.z)));
+                        nzn1 = -__logf(-__logf(u01_from_bits(pz.w)));
+                    } else { nz0 = nzn0; nz1 = nzn1; }
+                }
+                if (q == 0) { hand[4 + 2 * (ep_of_ts & 1u)] = nz0; hand[5 + 2 * (ep_of_ts & 1u)] = nz1; }
+            }
+        };
+        // S, window B4-B5: per-frame constants of the C quarter (c2 rzn, c3, c4) once the frame changed
+        auto s_frame_consts = [&]() {
+            if (pend_frame >= 0 && pend_frame != cst_frame) {
+                if (q == 0) {
+                    const int fi = pend_frame;
+                    cstQ[8] = C2g[(size_t)fi * 1536 + unit]; cstQ[9] = C2g[(size_t)fi * 1536 + 512 + unit];
+                    cstQ[10] = C2g[(size_t)fi * 1536 + 1024 + unit];
+                    cstQ[11] = C3g[(size_t)fi * 512 + unit];
+                    cstQ[12] = C4g[(size_t)fi * 512 + unit];
+                }
+                cst_frame = pend_frame;
+            }
+        };
+        if (!isC) {
+            if (q == 0) { hand[0] = cstQ[3]; hand[1] = cstQ[4]; hand[2] = cstQ[5]; }   // gh2 = b_hh2
+            cnext0 = CONDg[sidx]; cnext1 = CONDg[sidx + 256];
+            s_prepare(0, epoch + 1);
+            s_frame_consts();
+        }
+        __syncthreads();
+
+        for (int64_t t = 0; t < a.steps; ++t) {
+            ++epoch;
+            const unsigned par = epoch & 1u;
+
+            // ---- phase A (all 512 threads, unit j = tid): I + GRU1, replicated in every WG (:208-212) ----
+            float x2_j;
+            {
+                const float4 cA = ((const float4 *)(lds + L_CSTA))[tid];
+                const float4 cd = ((const float4 *)(lds + L_COND))[tid];
+                const float ghr = gh1s[tid], ghz = gh1s[512 + tid], ghn = gh1s[1024 + tid];
+                const float xprev = misc_f[M_XF];
+                const float xin = fmaf(cA.x, xprev, cd.x);
+                const float rg = sigmoid_fast(fmaf(cA.y, xprev, cd.y) + ghr);
+                const float zg = sigmoid_fast(fmaf(cA.z, xprev, cd.z) + ghz);
+                const float ng = tanh_fast(fmaf(cA.w, xprev, cd.w) + rg * ghn);
+                h1_j = (1.0f - zg) * ng + zg * h1_j;
+                x2_j = xin + h1_j;
+                xb[XB_H1 * 512 + pj] = h1_j;
+                xb[XB_X2 * 512 + pj] = x2_j;
+            }
+            __syncthreads();  // B1
+
+            if (isC) {
+                // ---- phase B: GRU2 unit `unit` (:213-216); rows r,z,n of W_ih2[:, :512] . x2 ----
+                const float h2o = xb[XB_H2 * 512 + pu];
+                const float x2u = xb[XB_X2 * 512 + pu];
+                const float g2r = hand[0], g2z = hand[1], g2n = hand[2];
+                const float c2r = cstQ[8], c2z = cstQ[9], c2n = cstQ[10];
+                float gr, gz, gn;
+                dot32x3(wv, xb + XB_X2 * 512, q, gr, gz, gn);
+                gr = row_sum(gr) + c2r; gz = row_sum(gz) + c2z; gn = row_sum(gn) + c2n;
+                const float rg = sigmoid_fast(gr + g2r);
+                const float zg = sigmoid_fast(gz + g2z);
+                const float ng = tanh_fast(gn + rg * g2n);
+                const float x3u = x2u + ((1.0f - zg) * ng + zg * h2o);
+                if (q == 0) st_granule(mail, G_X3 + par * 512 + unit, epoch, __float_as_uint(x3u));
+                __builtin_amdgcn_s_sleep(3);   // first look ~250 cycles after the publish (see loop_team.hip)
+            } else {
+                // ---- S: gh1 for the next step = W_hh1 . h1' + b_hh1, published for everyone ----
+                float sr, sz, sn;
+                dot32x3(wv, xb + XB_H1 * 512, q, sr, sz, sn);
+                sr = row_sum(sr) + cstQ[0]; sz = row_sum(sz) + cstQ[1]; sn = row_sum(sn) + cstQ[2];
+                if (q == 0) {
+                    st_granule(mail, G_GH + par * 1536 + unit, epoch, __float_as_uint(sr));
+                    st_granule(mail, G_GH + par * 1536 + 512 + unit, epoch, __float_as_uint(sz));
+                    st_granule(mail, G_GH + par * 1536 + 1024 + unit, epoch, __float_as_uint(sn));
+                }
+            }
+            // ---- exchange 1 (all threads, granule tid): x3 = x + h2 ; h2' = x3 - x2 ----
+            {
+                u64 gq[1];
+                peek_n<1>(mail, G_X3 + par * 512 + tid, 1, gq);
+                finish_n<1, 32>(mail, G_X3 + par * 512 + tid, 1, epoch, gq, dead, a.err, 11u);
+                const float x3 = __uint_as_float((unsigned)gq[0]);
+                xb[XB_X3 * 512 + pj] = x3;
+                xb[XB_H2 * 512 + pj] = x3 - x2_j;
+            }
+            __syncthreads();  // B2
+
+            if (isC) {
+                // ---- phase C: fc1 row `unit` (:217-218) ----
+                const float s = row_sum(dot32(wv + 128, xb + XB_X3 * 512, q)) + cstQ[11];
+                if (q == 0) st_granule(mail, G_F1 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
+                __builtin_amdgcn_s_sleep(3);
+            } else {
+                // ---- S: gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter ----
+                float sr, sz, sn;
+                dot32x3_mixed(wv + 96, swl, xb + XB_H2 * 512, q, sr, sz, sn);
+                sr = row_sum(sr) + cstQ[3]; sz = row_sum(sz) + cstQ[4]; sn = row_sum(sn) + cstQ[5];
+                if (q == 0) { hand[0] = sr; hand[1] = sz; hand[2] = sn; }
+            }
+            // ---- exchange 2: fc1 outputs ----
+            {
+                u64 gq[1];
+                peek_n<1>(mail, G_F1 + par * 512 + tid, 1, gq);
+                finish_n<1, 32>(mail, G_F1 + par * 512 + tid, 1, epoch, gq, dead, a.err, 12u);
+                xb[XB_F1 * 512 + pj] = __uint_as_float((unsigned)gq[0]);
+            }
+            __syncthreads();  // B3
+
+            if (isC) {
+                // ---- phase D: fc2 row `unit` (:220-221) ----
+                const float s = row_sum(dot32(wv + 96, xb + XB_F1 * 512, q)) + cstQ[12];
+                if (q == 0) st_granule(mail, G_F2 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
+                __builtin_amdgcn_s_sleep(3);
+            } else {
+                // ---- S: conditioning + noise of step t+1 ----
+                if (t + 1 < a.steps) s_prepare(t + 1, epoch + 1);
+            }
+            // ---- exchange 3: fc2 outputs ----
+            {
+                u64 gq[1];
+                peek_n<1>(mail, G_F2 + par * 512 + tid, 1, gq);
+                finish_n<1, 32>(mail, G_F2 + par * 512 + tid, 1, epoch, gq, dead, a.err, 13u);
+                xb[XB_F2 * 512 + pj] = __uint_as_float((unsigned)gq[0]);
+            }
+            __syncthreads();  // B4
+
+            if (isC) {
+                // ---- phase E: fc3 rows + race (:223, :231-235) ----
+                float lg0, lg1;
+                {
+                    const float4 *xp = (const float4 *)(xb + XB_F2 * 512) + q;
+                    const float4 *wp = (const float4 *)(lds + L_FC3) + (size_t)(wl * 2) * 8 * 64 + lane;
+                    f2 pa = mk2(0.f, 0.f), pb = mk2(0.f, 0.f);
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk += 4) {
+                        float4 x[4], wa[4], wb[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { x[k] = xp[(kk + k) * 16]; wa[k] = wp[(kk + k) * 64]; wb[k] = wp[(8 + kk + k) * 64]; }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f2 xl = mk2(x[k].x, x[k].y), xh = mk2(x[k].z, x[k].w);
+                            pa = pkfma(mk2(wa[k].x, wa[k].y), xl, pa); pb = pkfma(mk2(wb[k].x, wb[k].y), xl, pb);
+                            pa = pkfma(mk2(wa[k].z, wa[k].w), xh, pa); pb = pkfma(mk2(wb[k].z, wb[k].w), xh, pb);
+                        }
+                    }
+                    lg0 = row_sum(pa.x + pa.y) + cstQ[6];
+                    lg1 = row_sum(pb.x + pb.y) + cstQ[7];
+                }
+                if (a.logits_out && q == 0 && has_fc3) {
+                    float *lo = a.logits_out + ((size_t)t * a.n_rows + row) * NC + c3row0;
+                    lo[0] = lg0;
+                    if (c3row0 + 1 < NC) lo[1] = lg1;
+                }
+                if (MODE == WRNN_MODE_RAW) {
+                    // winner of this quarter-wave's 2 classes: argmax logit_k - log q_k
+                    const float v0 = lg0 + hand[4 + 2 * par], v1 = lg1 + hand[5 + 2 * par];
+                    const bool p1 = v1 > v0;
+                    if (q == 0) st_granule(mail, G_PR + par * 512 + 16 * g + qslot,
+                                           (epoch << 10) | (unsigned)(p1 ? c3row0 + 1 : c3row0), __float_as_uint(p1 ? v1 : v0));
+                    if (wave == 0) {
+                        // ---- exchange 4: 512 {value,index} granules, 8 per lane; race winner ----
+                        __builtin_amdgcn_s_sleep(3);
+                        u64 gq[8];
+                        peek_n<8>(mail, G_PR + par * 512 + lane * 8, 1, gq);
+                        finish_n<8, 42>(mail, G_PR + par * 512 + lane * 8, 1, epoch & 0x3fffffu, gq, dead, a.err, 14u);
+                        float best = -INFINITY; int besti = 0;
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) {
+                            const float vv = __uint_as_float((unsigned)gq[m]);
+                            const int ii = (int)((gq[m] >> 32) & 1023u);
+                            if (vv > best || (vv == best && ii < besti)) { best = vv; besti = ii; }
+                        }
+                        const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max(best)), 63));
+                        const u64 ball = __ballot(best == mx);
+                        const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
+                        const int k = __builtin_amdgcn_readlane(besti, src);
+                        if (lane == 0) {
+                            // sample = 2 * k / (n_classes - 1.) - 1.   (:235)
+                            const float x_new = 2.0f * (float)k / ((float)NC - 1.0f) - 1.0f;
+                            misc_f[M_XF] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + row] : x_new;   // (:237)
+                            if (g == 0) {
+                                if (a.labels_out) a.labels_out[(size_t)row * a.steps + t] = k;
+                                a.samples_out[(size_t)row * a.steps + t] = x_new;
+                            }
+                        }
+                    }
+                } else {
+                    // MOL (distribution.py:87-123): the 30 fc3 outputs are exchanged, wave 0 of every WG samples
+                    if (q == 0 && has_fc3) {
+                        st_granule(mail, G_PR + par * 512 + c3row0, epoch, __float_as_uint(lg0));
+                        if (c3row0 + 1 < NC) st_granule(mail, G_PR + par * 512 + c3row0 + 1, epoch, __float_as_uint(lg1));
+                    }
+                    if (wave == 0) {
+                        const int nr = NC / 3;
+                        float mylg = 0.0f;
+                        if (lane < NC) {
+                            u64 gq[1];
+                            peek_n<1>(mail, G_PR + par * 512 + lane, 1, gq);
+                            unsigned spins = 0;
+                            while (!dead && (unsigned)(gq[0] >> 32) != epoch) {
+                                if (++spins > T2_SPIN_MAX) { dead = true; atomicExch(a.err, 16u); break; }
+                                peek_n<1>(mail, G_PR + par * 512 + lane, 1, gq);
+                            }
+                            mylg = __uint_as_float((unsigned)gq[0]);
+                        }
+                        float v = -INFINITY;
+                        if (lane < nr) {
+                            float u1;
+                            if (a.noise_mode == WRNN_NOISE_INJECTED) u1 = a.noise1[((size_t)t * a.n_rows + row) * nr + lane];
+                            else u1 = 1e-5f + wrnn_uniform(a.seed, (uint64_t)t, (uint32_t)row, (uint32_t)lane) * (1.0f - 2e-5f);
+                            v = mylg - logf(-logf(u1));
+                        }
+                        const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max(v)), 63));
+                        const u64 ball = __ballot(v == mx);
+                        const int km = (int)__builtin_ctzll(ball ? ball : 1ull);
+                        const float mean = __shfl(mylg, nr + km, 64);
+                        const float ls = fmaxf(__shfl(mylg, 2 * nr + km, 64), -32.23619130191664f);
+                        float u2;
+                        if (a.noise_mode == WRNN_NOISE_INJECTED) u2 = a.noise2[(size_t)t * a.n_rows + row];
+                        else u2 = 1e-5f + wrnn_uniform(a.seed, (uint64_t)t, (uint32_t)row, 10u) * (1.0f - 2e-5f);
+                        float xs = mean + expf(ls) * (logf(u2) - logf(1.0f - u2));
+                        xs = fminf(fmaxf(xs, -1.0f), 1.0f);
+                        if (lane == 0) {
+                            misc_f[M_XF] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + row] : xs;
+                            if (g == 0) {
+                                if (a.labels_out) a.labels_out[(size_t)row * a.steps + t] = km;
+                                a.samples_out[(size_t)row * a.steps + t] = xs;
+                            }
+                        }
+                    }
+                }
+            } else {
+                // ---- S, window B4-B5: per-frame constants for the C quarter, then the gh1 gather (6 granules / thread) ----
+                s_frame_consts();
+                u64 gq[6];
+                peek_n<6>(mail, G_GH + par * 1536 + sidx, 256, gq);
+                finish_n<6, 32>(mail, G_GH + par * 1536 + sidx, 256, epoch, gq, dead, a.err, 15u);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) gh1s[sidx + m * 256] = __uint_as_float((unsigned)gq[m]);
+            }
+            __syncthreads();  // B5
+            if ((t & 63) == 63) {   // bounded-spin bail-out, checked workgroup-wide every 64 steps
+                if (dead && lane == 0) misc_i[M_DEAD] = 1;
+                __syncthreads();
+                if (misc_i[M_DEAD]) return;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)L_TOTAL * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_MOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (a.d.mode == WRNN_MODE_RAW)
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW>), dim3(256), dim3(T2_THREADS), lds, s, a);
+    else
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_MOL>), dim3(256), dim3(T2_THREADS), lds, s, a);
+    return hipGetLastError();
+}

@@ -254,3 +254,47 @@ hipError_t wrnn_launch_pack_records(const float *CM, const float *CA, const floa
     hipLaunchKernelGGL(pack_records_kernel, dim3(T + 1, B), dim3(256), 0, s, CM, CA, VM, VA, rec, T, P);
     return hipGetLastError();
 }
+
+// Per-step phase-A conditioning stream for WRNN_KERNEL_TEAM2: cond[row][t][j] = {cI, v_r, v_z, v_n} of hidden unit j
+// at loop step t, i.e. the conditioning of the I layer and of GRU1's input gates with the (5,5,11) upsampling taps
+// already applied:  c[t] = rec.A + sum_d k[phase(t)][d] * rec.M[d]   (records: pack_records_kernel).
+// 8 KB per step, written once as a coalesced HBM stream (0.9 GB for a 5 s clip, ~0.2 ms at HBM speed) and read once
+// per step by the 32 workgroups of a team (1 HBM read + 31 L2 hits).  grid (ceil(steps/64), rows), block 512 (= unit).
+__global__ void __launch_bounds__(512)
+cond_stream_kernel(const float *__restrict__ rec, const float *__restrict__ ktab, const WrnnRow *__restrict__ rows,
+                   float4 *__restrict__ cond, int T, int HOP, long total_len, long steps) {
+    const int j = threadIdx.x, row = blockIdx.y;
+    const WrnnRow rw = rows[row];
+    const float *recb = rec + (size_t)rw.utt * (T + 1) * 512 * 28;
+    const long t0 = (long)blockIdx.x * 64;
+    const long t1 = t0 + 64 < steps ? t0 + 64 : steps;
+    int cur = -1;
+    float4 a0, a1, a2, a3, a4, a5;
+    a0 = a1 = a2 = a3 = a4 = a5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long t = t0; t < t1; ++t) {
+        const long pos = rw.start + t;
+        const bool live = pos < total_len;            // fold padding 'after' = zero rows (fatchord_version.py:327-330)
+        const int fi = live ? (int)(pos / HOP) : T;   // T = the all-zero conditioning record
+        const int ph = live ? (int)(pos - (long)fi * HOP) : 0;
+        if (fi != cur) {
+            const float4 *r = (const float4 *)(recb + ((size_t)fi * 512 + j) * 28);
+            a0 = r[0]; a1 = r[1]; a2 = r[2]; a3 = r[3]; a4 = r[4]; a5 = r[5];
+            cur = fi;
+        }
+        const float k0 = ktab[ph * 5 + 0], k1 = ktab[ph * 5 + 1], k2 = ktab[ph * 5 + 2], k3 = ktab[ph * 5 + 3], k4 = ktab[ph * 5 + 4];
+        // record: {CA, VAr, VAz, VAn | CM0..3 | CM4, VM0r, VM0z, VM0n | VM1r, VM1z, VM1n, VM2r | VM2z, VM2n, VM3r, VM3z | VM3n, VM4r, VM4z, VM4n}
+        float4 c;
+        c.x = fmaf(k4, a2.x, fmaf(k3, a1.w, fmaf(k2, a1.z, fmaf(k1, a1.y, fmaf(k0, a1.x, a0.x)))));
+        c.y = fmaf(k4, a5.y, fmaf(k3, a4.z, fmaf(k2, a3.w, fmaf(k1, a3.x, fmaf(k0, a2.y, a0.y)))));
+        c.z = fmaf(k4, a5.z, fmaf(k3, a4.w, fmaf(k2, a4.x, fmaf(k1, a3.y, fmaf(k0, a2.z, a0.z)))));
+        c.w = fmaf(k4, a5.w, fmaf(k3, a5.x, fmaf(k2, a4.y, fmaf(k1, a3.z, fmaf(k0, a2.w, a0.w)))));
+        cond[((size_t)row * steps + t) * 512 + j] = c;
+    }
+}
+
+hipError_t wrnn_launch_cond_stream(const float *rec, const float *ktab, const WrnnRow *rows, float *cond, int n_rows, int T,
+                                   int HOP, long total_len, long steps, hipStream_t s) {
+    dim3 grid((unsigned)((steps + 63) / 64), n_rows);
+    hipLaunchKernelGGL(cond_stream_kernel, grid, dim3(512), 0, s, rec, ktab, rows, (float4 *)cond, T, HOP, total_len, steps);
+    return hipGetLastError();
+}

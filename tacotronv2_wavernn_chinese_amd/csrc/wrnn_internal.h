@@ -80,6 +80,8 @@ struct wrnn_handle {
     float *team_w = nullptr, *team_fc3 = nullptr, *wI0 = nullptr, *u1 = nullptr;
     float *tab = nullptr;         // CM|CA|VM|VA|C2|C3|C4 for the current batch
     size_t tab_cap = 0;
+    float *cond = nullptr;        // per-step conditioning stream (TEAM2)
+    size_t cond_cap = 0;
     unsigned long long *mail = nullptr;
     unsigned *ctl = nullptr;
     unsigned long long *prof = nullptr;   // set when WRNN_TEAM_PROF=1 in the environment
@@ -131,6 +133,7 @@ struct WrnnTeamArgs {
     //   VM (T+2P,3H) = W_ih1 . CM[f]                VA (T+1,3H) = W_ih1 . CA[i] + b_ih1
     // packed per frame and hidden unit, see pack_records_kernel (prologue.hip)
     const float *tabREC;      // (B, T+1, H, 28)
+    const float *tabCOND;     // (rows, steps, H, 4) per-step phase-A conditioning stream (TEAM2) or null
     const float *tabC2;       // (B, T+1, 3H)   W_ih2[:,H:] . a2[i] + b_ih2
     const float *tabC3;       // (B, T+1, FC)   fc1.W[:,H:] . a3[i] + b1
     const float *tabC4;       // (B, T+1, FC)   fc2.W[:,FC:] . a4[i] + b2
@@ -161,6 +164,9 @@ hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, cons
                                    int T, float *up, float *aux_up, hipStream_t s);
 hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
 hipError_t wrnn_launch_loop_team(const WrnnTeamArgs &a, hipStream_t s);
+hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s);
+hipError_t wrnn_launch_cond_stream(const float *rec, const float *ktab, const WrnnRow *rows, float *cond, int n_rows, int T,
+                                   int HOP, long total_len, long steps, hipStream_t s);
 hipError_t wrnn_launch_pack_records(const float *CM, const float *CA, const float *VM, const float *VA, float *rec, int B,
                                     int T, int P, hipStream_t s);
 // out[b][f][n] = bias[n] + sum_k in(b,f,k) * Wt[k*ldw + n]; mode 0: row-major src (rows >= valid read as 0),

@@ -23,7 +23,7 @@ def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 41
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     modes = ('RAW',) if len(sys.argv) > 3 and sys.argv[3] == 'raw' else ('RAW', 'MOL')
-    kernels = (('team', _cabi.KERNEL_TEAM),) if len(sys.argv) > 4 and sys.argv[4] == 'team' else (('simple', _cabi.KERNEL_SIMPLE), ('team', _cabi.KERNEL_TEAM))
+    kernels = (('team', _cabi.KERNEL_TEAM), ('team2', _cabi.KERNEL_TEAM2)) if len(sys.argv) > 4 and sys.argv[4] == 'team' else (('simple', _cabi.KERNEL_SIMPLE), ('team', _cabi.KERNEL_TEAM), ('team2', _cabi.KERNEL_TEAM2))
     for mode in modes:
         m = model(mode)
         mels = make_mels(3, B, T)
@@ -40,8 +40,10 @@ def main():
                       f'-> {steps / tm["loop_ms"]:.1f} ksamples/s, {tm["loop_ms"] * 1e3 / tm["steps"]:.2f} us/step (wall {dt:.2f}s)')
             except Exception as e:  # noqa
                 print(f'{mode} {name}: FAILED {e!r}')
-        if len(out) == 2:
-            a, b = out['simple'], out['team']
+        names = list(out)
+        for other in names[1:]:
+            a, b = out[names[0]], out[other]
+            print(f'  {names[0]} vs {other}:', end=' ')
             if mode == 'RAW':
                 mism = np.argwhere(a[0] != b[0])
                 print(f'  labels equal: {mism.size == 0}; first mismatch {mism[0] if mism.size else None}; n={len(mism)}')
