@@ -491,12 +491,12 @@ int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out) {
     unsigned errw = 0;
     HIP_TRY(h, hipMemcpy(&errw, h->err_dev, sizeof(errw), hipMemcpyDeviceToHost));
     if (out) *out = h->last;
-    if (h->prof && h->last.kernel == WRNN_KERNEL_TEAM) {
+    if (h->prof && (h->last.kernel == WRNN_KERNEL_TEAM || h->last.kernel == WRNN_KERNEL_TEAM2)) {
         unsigned long long pr[8 * 17];
         HIP_TRY(h, hipMemcpy(pr, h->prof, sizeof(pr), hipMemcpyDeviceToHost));
         const double n = (double)h->last.steps * ((h->last.rows + 7) / 8);
         for (int wv = 0; wv < 8; ++wv) {
-            fprintf(stderr, "[wrnn prof] wg%d wave%d cycles/step:", wv < 4 ? 0 : 31, wv & 3);
+            fprintf(stderr, "[wrnn prof] %s %d cycles/step:", h->last.kernel == WRNN_KERNEL_TEAM2 ? "team2 wg0 wave" : (wv < 4 ? "team wg0 wave" : "team wg31 wave"), h->last.kernel == WRNN_KERNEL_TEAM2 ? wv : (wv & 3));
             double tot = 0;
             for (int i = 0; i < 17; ++i) { fprintf(stderr, " %.0f", pr[wv * 17 + i] / n); tot += pr[wv * 17 + i] / n; }
             fprintf(stderr, " | total %.0f\n", tot);

@@ -174,7 +174,16 @@ constexpr unsigned G_X3 = 0, G_F1 = 1024, G_F2 = 2048, G_PR = 3072, G_GH = 4096;
 
 }  // namespace
 
-template <int MODE>
+#define P2(i)                                                               \
+    do {                                                                    \
+        if (PROF) {                                                         \
+            const u64 now_ = __builtin_readcyclecounter();                  \
+            prof_acc[i] += now_ - prof_last;                                \
+            prof_last = now_;                                               \
+        }                                                                   \
+    } while (0)
+
+template <int MODE, bool PROF>
 __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
@@ -252,6 +261,8 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 
     bool dead = false;
     unsigned epoch = 0;
+    u64 prof_acc[17] = {0};
+    u64 prof_last = 0;
 
     for (int row = team; row < a.n_rows; row += a.n_teams) {
         const WrnnRow rw = a.rows[row];
@@ -270,6 +281,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         int cst_frame = -1000000;   // frame whose c2/c3/c4 are in the C constants
         int pend_frame = -1;        // frame whose constants must be written in the next B4-B5 window
         float nzn0 = 0.f, nzn1 = 0.f;
+        float xfeed = 0.0f;   // x_{t-1} (:196)
         float4 cnext0 = make_float4(0.f, 0.f, 0.f, 0.f), cnext1 = cnext0;   // conditioning prefetched two steps ahead
 
         // S: everything of step ts that does not depend on x_{ts-1}: its conditioning (prefetched from the HBM
@@ -286,6 +298,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 cnext0 = CONDg[(size_t)(ts + 1) * 512 + sidx];
                 cnext1 = CONDg[(size_t)(ts + 1) * 512 + sidx + 256];
             }
+        };
+        // S: sampling noise of step ts for the paired C quarter -> hand[4 + 2*parity(ts) ...]
+        auto s_noise = [&](int64_t ts, unsigned ep_of_ts) {
             if (MODE == WRNN_MODE_RAW && has_fc3) {
                 float nz0 = 0.f, nz1 = 0.f;
                 if (a.noise_mode == WRNN_NOISE_INJECTED) {
@@ -321,6 +336,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             if (q == 0) { hand[0] = cstQ[3]; hand[1] = cstQ[4]; hand[2] = cstQ[5]; }   // gh2 = b_hh2
             cnext0 = CONDg[sidx]; cnext1 = CONDg[sidx + 256];
             s_prepare(0, epoch + 1);
+            s_noise(0, epoch + 1);
             s_frame_consts();
         }
         __syncthreads();
@@ -328,6 +344,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         for (int64_t t = 0; t < a.steps; ++t) {
             ++epoch;
             const unsigned par = epoch & 1u;
+            if (PROF) prof_last = __builtin_readcyclecounter();
 
             // ---- phase A (all 512 threads, unit j = tid): I + GRU1, replicated in every WG (:208-212) ----
             float x2_j;
@@ -335,7 +352,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 const float4 cA = ((const float4 *)(lds + L_CSTA))[tid];
                 const float4 cd = ((const float4 *)(lds + L_COND))[tid];
                 const float ghr = gh1s[tid], ghz = gh1s[512 + tid], ghn = gh1s[1024 + tid];
-                const float xprev = misc_f[M_XF];
+                const float xprev = xfeed;
                 const float xin = fmaf(cA.x, xprev, cd.x);
                 const float rg = sigmoid_fast(fmaf(cA.y, xprev, cd.y) + ghr);
                 const float zg = sigmoid_fast(fmaf(cA.z, xprev, cd.z) + ghz);
@@ -345,7 +362,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 xb[XB_H1 * 512 + pj] = h1_j;
                 xb[XB_X2 * 512 + pj] = x2_j;
             }
+            P2(0);
             __syncthreads();  // B1
+            P2(1);
 
             if (isC) {
                 // ---- phase B: GRU2 unit `unit` (:213-216); rows r,z,n of W_ih2[:, :512] . x2 ----
@@ -373,6 +392,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                     st_granule(mail, G_GH + par * 1536 + 1024 + unit, epoch, __float_as_uint(sn));
                 }
             }
+            P2(2);
             // ---- exchange 1 (all threads, granule tid): x3 = x + h2 ; h2' = x3 - x2 ----
             {
                 u64 gq[1];
@@ -382,7 +402,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 xb[XB_X3 * 512 + pj] = x3;
                 xb[XB_H2 * 512 + pj] = x3 - x2_j;
             }
+            P2(3);
             __syncthreads();  // B2
+            P2(4);
 
             if (isC) {
                 // ---- phase C: fc1 row `unit` (:217-218) ----
@@ -390,12 +412,10 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 if (q == 0) st_granule(mail, G_F1 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
                 __builtin_amdgcn_s_sleep(3);
             } else {
-                // ---- S: gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter ----
-                float sr, sz, sn;
-                dot32x3_mixed(wv + 96, swl, xb + XB_H2 * 512, q, sr, sz, sn);
-                sr = row_sum(sr) + cstQ[3]; sz = row_sum(sz) + cstQ[4]; sn = row_sum(sn) + cstQ[5];
-                if (q == 0) { hand[0] = sr; hand[1] = sz; hand[2] = sn; }
+                // ---- S: sampling noise of step t+1 (C reads the other parity slot this step) ----
+                if (t + 1 < a.steps) s_noise(t + 1, epoch + 1);
             }
+            P2(5);
             // ---- exchange 2: fc1 outputs ----
             {
                 u64 gq[1];
@@ -403,7 +423,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 finish_n<1, 32>(mail, G_F1 + par * 512 + tid, 1, epoch, gq, dead, a.err, 12u);
                 xb[XB_F1 * 512 + pj] = __uint_as_float((unsigned)gq[0]);
             }
+            P2(6);
             __syncthreads();  // B3
+            P2(7);
 
             if (isC) {
                 // ---- phase D: fc2 row `unit` (:220-221) ----
@@ -414,6 +436,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 // ---- S: conditioning + noise of step t+1 ----
                 if (t + 1 < a.steps) s_prepare(t + 1, epoch + 1);
             }
+            P2(8);
             // ---- exchange 3: fc2 outputs ----
             {
                 u64 gq[1];
@@ -421,7 +444,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 finish_n<1, 32>(mail, G_F2 + par * 512 + tid, 1, epoch, gq, dead, a.err, 13u);
                 xb[XB_F2 * 512 + pj] = __uint_as_float((unsigned)gq[0]);
             }
+            P2(9);
             __syncthreads();  // B4
+            P2(10);
 
             if (isC) {
                 // ---- phase E: fc3 rows + race (:223, :231-235) ----
@@ -456,32 +481,24 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                     const bool p1 = v1 > v0;
                     if (q == 0) st_granule(mail, G_PR + par * 512 + 16 * g + qslot,
                                            (epoch << 10) | (unsigned)(p1 ? c3row0 + 1 : c3row0), __float_as_uint(p1 ? v1 : v0));
-                    if (wave == 0) {
-                        // ---- exchange 4: 512 {value,index} granules, 8 per lane; race winner ----
+                    P2(13);
+                    {
+                        // ---- exchange 4: 512 {value,index} granules, 2 per lane over the 4 C waves; each wave leaves its
+                        // winner in LDS, every thread merges the four after B5 (no serial tail on one wave) ----
                         __builtin_amdgcn_s_sleep(3);
-                        u64 gq[8];
-                        peek_n<8>(mail, G_PR + par * 512 + lane * 8, 1, gq);
-                        finish_n<8, 42>(mail, G_PR + par * 512 + lane * 8, 1, epoch & 0x3fffffu, gq, dead, a.err, 14u);
-                        float best = -INFINITY; int besti = 0;
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) {
-                            const float vv = __uint_as_float((unsigned)gq[m]);
-                            const int ii = (int)((gq[m] >> 32) & 1023u);
-                            if (vv > best || (vv == best && ii < besti)) { best = vv; besti = ii; }
-                        }
+                        u64 gq[2];
+                        peek_n<2>(mail, G_PR + par * 512 + wl * 128 + lane * 2, 1, gq);
+                        finish_n<2, 42>(mail, G_PR + par * 512 + wl * 128 + lane * 2, 1, epoch & 0x3fffffu, gq, dead, a.err, 14u);
+                        P2(14);
+                        const float va = __uint_as_float((unsigned)gq[0]), vb = __uint_as_float((unsigned)gq[1]);
+                        const bool pb_ = vb > va;
+                        const float best = pb_ ? vb : va;
+                        const int besti = (int)(((pb_ ? gq[1] : gq[0]) >> 32) & 1023u);
                         const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max(best)), 63));
                         const u64 ball = __ballot(best == mx);
                         const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
                         const int k = __builtin_amdgcn_readlane(besti, src);
-                        if (lane == 0) {
-                            // sample = 2 * k / (n_classes - 1.) - 1.   (:235)
-                            const float x_new = 2.0f * (float)k / ((float)NC - 1.0f) - 1.0f;
-                            misc_f[M_XF] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + row] : x_new;   // (:237)
-                            if (g == 0) {
-                                if (a.labels_out) a.labels_out[(size_t)row * a.steps + t] = k;
-                                a.samples_out[(size_t)row * a.steps + t] = x_new;
-                            }
-                        }
+                        if (lane == 0) { misc_f[16 + 2 * wl] = mx; misc_i[17 + 2 * wl] = k; }
                     }
                 } else {
                     // MOL (distribution.py:87-123): the 30 fc3 outputs are exchanged, wave 0 of every WG samples
@@ -536,8 +553,34 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 finish_n<6, 32>(mail, G_GH + par * 1536 + sidx, 256, epoch, gq, dead, a.err, 15u);
 #pragma unroll
                 for (int m = 0; m < 6; ++m) gh1s[sidx + m * 256] = __uint_as_float((unsigned)gq[m]);
+                P2(13);
+                // gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter (C read the old
+                // value back in phase B, two barriers ago)
+                float sr, sz, sn;
+                dot32x3_mixed(wv + 96, swl, xb + XB_H2 * 512, q, sr, sz, sn);
+                sr = row_sum(sr) + cstQ[3]; sz = row_sum(sz) + cstQ[4]; sn = row_sum(sn) + cstQ[5];
+                if (q == 0) { hand[0] = sr; hand[1] = sz; hand[2] = sn; }
             }
+            P2(11);
             __syncthreads();  // B5
+            P2(12);
+            if (MODE == WRNN_MODE_RAW) {
+                // merge the four per-wave race winners (ties -> lower wave = lower class index range)
+                const float4 m0 = *(const float4 *)(misc_f + 16), m1 = *(const float4 *)(misc_f + 20);
+                float bv = m0.x; int bk = __float_as_int(m0.y);
+                if (m0.z > bv) { bv = m0.z; bk = __float_as_int(m0.w); }
+                if (m1.x > bv) { bv = m1.x; bk = __float_as_int(m1.y); }
+                if (m1.z > bv) { bv = m1.z; bk = __float_as_int(m1.w); }
+                // sample = 2 * k / (n_classes - 1.) - 1.   (:235)
+                const float x_new = 2.0f * (float)bk / ((float)NC - 1.0f) - 1.0f;
+                xfeed = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + row] : x_new;   // (:237)
+                if (g == 0 && tid == 0) {
+                    if (a.labels_out) a.labels_out[(size_t)row * a.steps + t] = bk;
+                    a.samples_out[(size_t)row * a.steps + t] = x_new;
+                }
+            } else {
+                xfeed = misc_f[M_XF];
+            }
             if ((t & 63) == 63) {   // bounded-spin bail-out, checked workgroup-wide every 64 steps
                 if (dead && lane == 0) misc_i[M_DEAD] = 1;
                 __syncthreads();
@@ -546,21 +589,28 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         }
         __syncthreads();
     }
+    if (PROF && a.prof && lane == 0 && g == 0) {
+        for (int i = 0; i < 17; ++i) a.prof[wave * 17 + i] = prof_acc[i];
+    }
 }
 
 hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_RAW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_MOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_MOL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (a.d.mode == WRNN_MODE_RAW)
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW>), dim3(256), dim3(T2_THREADS), lds, s, a);
+    if (a.prof && a.d.mode == WRNN_MODE_RAW) {
+        hipError_t e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_RAW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, true>), dim3(256), dim3(T2_THREADS), lds, s, a);
+    } else if (a.d.mode == WRNN_MODE_RAW)
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, false>), dim3(256), dim3(T2_THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_MOL>), dim3(256), dim3(T2_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_MOL, false>), dim3(256), dim3(T2_THREADS), lds, s, a);
     return hipGetLastError();
 }
