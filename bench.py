@@ -39,9 +39,10 @@ SAMPLE_RATE = 22050
 BYTES_PER_SAMPLE_B1 = 17_371_136 + 836   # W + (C + O) at B = 1
 FLOP_PER_SAMPLE = 8_668_160
 HBM_PEAK = 8.0e12                   # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of one loop-kernel launch on the T=401 workload from the PMC passes in profiles/r01_rocprofv3_bench_team.txt
+# HBM bytes of one loop-kernel launch on the T=401 workload from the PMC passes in profiles/r01_rocprofv3_bench_team*.txt
 # (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE): weights once + per-frame records
-TRAFFIC_BYTES_PER_LAUNCH = int((20082.2 * 2 + 1309.6) * 1024)
+TRAFFIC_BYTES_PER_LAUNCH = {2: int((20082.2 * 2 + 1309.6) * 1024),    # team : weights once + per-frame records
+                            3: 923_299_008}                           # team2: weights once + the 8 KB/step conditioning stream
 
 
 def cpu_baseline(frames: int = 61, max_threads: int = 16) -> dict:
@@ -158,7 +159,7 @@ def main() -> int:
                        'prologue_ms': round(float(np.mean(pro_ms)), 3), 'loop_kernel_ms': round(k_ms, 3),
                        'parallelism': f'utterance-parallel x{world} (no data-path collective)'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved / 1e9, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK, 4), 'traffic': TRAFFIC_BYTES_PER_LAUNCH if T == T_FRAMES else None,
+                         'frac': round(achieved / HBM_PEAK, 4), 'traffic': TRAFFIC_BYTES_PER_LAUNCH.get(kernel_ran) if T == T_FRAMES else None,
                          'note': 'achieved = algorithmic bytes (17 371 972 B/sample at B=1) x steps per launch / loop-kernel duration; '
                                  'traffic = measured HBM bytes per launch (PMC passes, profiles/): the weights are register/LDS '
                                  'resident, so the kernel is latency/issue-bound, not HBM-bound'},

@@ -224,6 +224,7 @@ __global__ void __launch_bounds__(SIMPLE_THREADS) loop_simple_kernel(WrnnLoopArg
 }  // namespace
 
 hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     hipLaunchKernelGGL(loop_simple_kernel, dim3(a.n_rows), dim3(SIMPLE_THREADS), 0, s, a);
     return hipGetLastError();
 }

@@ -666,6 +666,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
 }
 
 hipError_t wrnn_launch_loop_team(const WrnnTeamArgs &a, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     static bool attr_set = false;
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
     if (!attr_set) {

@@ -10,12 +10,17 @@
 // (W_hh1.h1, W_hh2.h2, conditioning and noise of the next step, the gh1 gather) plus 256 v_accvgpr_read for
 // weights parked in AGPRs.  So: 8 waves per workgroup, two per SIMD, and the two waves of a SIMD get different jobs:
 //   waves 0-3 "C" (critical): W_ih2 (96) + fc1 (32) + fc2 (32) weights in VGPRs, fc3 slice in LDS;
-//                             phases B, C, D, E and the race reduction (wave 0);
-//   waves 4-7 "S" (shadow):   W_hh1 (96) + W_hh2 (96) weights in VGPRs; gh1, gh2, next-step conditioning,
-//                             sampling noise, per-frame record refill, gh1 gather.
-// All 512 threads share phase A (unit j = tid) and the exchange polls (granule tid).  No AGPR parking is needed:
-// 2 waves/SIMD x 256 registers hold 192 (S) / 160 (C) weights + the working set.  S hands its results to C through
-// small LDS slots between the same 5 barriers.
+//                             phases B, C, D, E; each C wave reduces a quarter of the race winners;
+//   waves 4-7 "S" (shadow):   W_hh1 (96) + W_hh2 gates r,z (64) in VGPRs, W_hh2 gate n (32) in LDS;
+//                             window 2: gh1 = W_hh1.h1 (published), window 3: sampling noise of step t+1 (16 lanes of a
+//                             quarter-wave evaluate 16 different Philox blocks -> one evaluation per lane per 32 steps),
+//                             window 4: conditioning of step t+1 (LDS <- registers <- HBM stream, prefetched two steps
+//                             ahead), window 5: gh1 gather, gh2 = W_hh2.h2, per-frame constants.
+// All 512 threads share phase A (unit j = tid), the exchange polls (granule tid) and the final 4-way merge of the
+// race.  No AGPR parking: 2 waves/SIMD x 256 registers hold 160 weights + the working set.  S hands its results to C
+// through small LDS slots between the same 5 barriers.  The phase-A conditioning {cI, v_r, v_z, v_n}[512] of every step
+// is precomputed by cond_stream_kernel (prologue.hip) into an 8 KB/step HBM stream instead of being rebuilt from
+// per-frame records in LDS: 57 KB of LDS and ~70 instructions per step saved for 1.6 GB/s of HBM traffic.
 //
 // Thread map inside a role (wl = wave & 3, lane l: quarter r4 = l>>4, q = l&15): quarter-wave (wl, r4) owns hidden
 // unit / fc row u = 16 g + 4 wl + r4 and columns 32q..32q+31 of every row it owns.
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         int nfi = (int)(rw.start / HOP), nph = (int)(rw.start - (int64_t)nfi * HOP);
         int cst_frame = -1000000;   // frame whose c2/c3/c4 are in the C constants
         int pend_frame = -1;        // frame whose constants must be written in the next B4-B5 window
-        float nzn0 = 0.f, nzn1 = 0.f;
+        float nzE0 = 0.f, nzE1 = 0.f, nzn0 = 0.f, nzn1 = 0.f;   // this lane's Philox block: draws for an even / odd step
         float xfeed = 0.0f;   // x_{t-1} (:196)
         float4 cnext0 = make_float4(0.f, 0.f, 0.f, 0.f), cnext1 = cnext0;   // conditioning prefetched two steps ahead
 
@@ -294,9 +299,13 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             pend_frame = fi;
             ((float4 *)(lds + L_COND))[sidx] = cnext0;
             ((float4 *)(lds + L_COND))[sidx + 256] = cnext1;
-            if (ts + 1 < a.steps) {
-                cnext0 = CONDg[(size_t)(ts + 1) * 512 + sidx];
-                cnext1 = CONDg[(size_t)(ts + 1) * 512 + sidx + 256];
+        };
+        // S: HBM prefetch of the conditioning of step ts (consumed by s_prepare(ts) one step later).  Issued right
+        // before a stretch of ALU work so that no exchange poll queues behind these ~1 us loads.
+        auto s_prefetch = [&](int64_t ts) {
+            if (ts < a.steps) {
+                cnext0 = CONDg[(size_t)ts * 512 + sidx];
+                cnext1 = CONDg[(size_t)ts * 512 + sidx + 256];
             }
         };
         // S: sampling noise of step ts for the paired C quarter -> hand[4 + 2*parity(ts) ...]
@@ -306,17 +315,24 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 if (a.noise_mode == WRNN_NOISE_INJECTED) {
                     const float *qp = a.noise1 + ((size_t)ts * a.n_rows + row) * NC + c3row0;
                     nz0 = -logf(qp[0]); nz1 = -logf(qp[1]);
+                    if (q == 0) { hand[4 + 2 * (ep_of_ts & 1u)] = nz0; hand[5 + 2 * (ep_of_ts & 1u)] = nz1; }
                 } else if (a.noise_mode == WRNN_NOISE_PHILOX) {
-                    // one Philox block = classes (c3row0, c3row0+1) x steps (2s, 2s+1): evaluated on even steps
-                    if ((ts & 1) == 0) {
-                        const Philox4 pz = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)c3row0);
-                        nz0 = -__logf(-__logf(u01_from_bits(pz.x)));
-                        nz1 = -__logf(-__logf(u01_from_bits(pz.y)));
+                    // One Philox block = classes (c3row0, c3row0+1) x steps (2s, 2s+1).  The 16 lanes of the quarter-wave
+                    // evaluate 16 DIFFERENT blocks (the next 32 steps) at once instead of the same one 16 times: one
+                    // Philox evaluation per lane every 32 steps; the lane that owns step ts hands its draw over.
+                    if ((ts & 31) == 0) {
+                        const Philox4 pz = wrnn_raw_block(a.seed, (uint64_t)ts + 2u * (unsigned)q, (uint32_t)row, (uint32_t)c3row0);
+                        nzE0 = -__logf(-__logf(u01_from_bits(pz.x)));
+                        nzE1 = -__logf(-__logf(u01_from_bits(pz.y)));
                         nzn0 = -__logf(-__logf(u01_from_bits(pz.z)));
                         nzn1 = -__logf(-__logf(u01_from_bits(pz.w)));
-                    } else { nz0 = nzn0; nz1 = nzn1; }
-                }
-                if (q == 0) { hand[4 + 2 * (ep_of_ts & 1u)] = nz0; hand[5 + 2 * (ep_of_ts & 1u)] = nz1; }
+                    }
+                    if (q == (int)((ts >> 1) & 15)) {
+                        const bool odd = (ts & 1) != 0;
+                        hand[4 + 2 * (ep_of_ts & 1u)] = odd ? nzn0 : nzE0;
+                        hand[5 + 2 * (ep_of_ts & 1u)] = odd ? nzn1 : nzE1;
+                    }
+                } else if (q == 0) { hand[4 + 2 * (ep_of_ts & 1u)] = 0.f; hand[5 + 2 * (ep_of_ts & 1u)] = 0.f; }
             }
         };
         // S, window B4-B5: per-frame constants of the C quarter (c2 rzn, c3, c4) once the frame changed
@@ -334,8 +350,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         };
         if (!isC) {
             if (q == 0) { hand[0] = cstQ[3]; hand[1] = cstQ[4]; hand[2] = cstQ[5]; }   // gh2 = b_hh2
-            cnext0 = CONDg[sidx]; cnext1 = CONDg[sidx + 256];
+            s_prefetch(0);
             s_prepare(0, epoch + 1);
+            s_prefetch(1);
             s_noise(0, epoch + 1);
             s_frame_consts();
         }
@@ -554,6 +571,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 #pragma unroll
                 for (int m = 0; m < 6; ++m) gh1s[sidx + m * 256] = __uint_as_float((unsigned)gq[m]);
                 P2(13);
+                s_prefetch(t + 2);   // lands during gh2 and the next step's windows 1-3
                 // gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter (C read the old
                 // value back in phase B, two barriers ago)
                 float sr, sz, sn;
@@ -595,6 +613,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 }
 
 hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     static bool attr_set = false;
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
     if (!attr_set) {

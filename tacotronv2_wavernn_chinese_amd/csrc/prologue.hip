@@ -119,6 +119,7 @@ resnet_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const flo
 
 hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, float *aux_frames,
                               hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     const WrnnDims &d = h->d;
     dim3 grid((T + RESNET_FT - 1) / RESNET_FT, B);
     size_t lds = ((size_t)(RESNET_FT + d.KS - 1) * d.F + 2 * (size_t)RESNET_FT * d.C) * sizeof(float);
@@ -165,6 +166,7 @@ materialize_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, cons
 
 hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, const float *aux_frames, int B,
                                    int T, float *up, float *aux_up, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     const WrnnDims &d = h->d;
     const long L = (long)T * d.HOP;
     dim3 grid((unsigned)((L + 63) / 64), B);
@@ -213,6 +215,7 @@ frame_linear_kernel(const float *__restrict__ src, size_t src_bstride, int ld, i
 hipError_t wrnn_launch_frame_linear(int mode, const float *src, size_t src_bstride, int ld, int valid, const float *Wt,
                                     int ldw, const float *bias, float *out, size_t out_bstride, int frames, int K,
                                     int N, int B, int T, int P, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     dim3 grid((frames + 7) / 8, (N + 127) / 128, B);
     const size_t lds = (size_t)8 * K * sizeof(float);
     if (mode == 0)
@@ -251,6 +254,7 @@ pack_records_kernel(const float *__restrict__ CM, const float *__restrict__ CA, 
 
 hipError_t wrnn_launch_pack_records(const float *CM, const float *CA, const float *VM, const float *VA, float *rec, int B,
                                     int T, int P, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     hipLaunchKernelGGL(pack_records_kernel, dim3(T + 1, B), dim3(256), 0, s, CM, CA, VM, VA, rec, T, P);
     return hipGetLastError();
 }
@@ -294,6 +298,7 @@ cond_stream_kernel(const float *__restrict__ rec, const float *__restrict__ ktab
 
 hipError_t wrnn_launch_cond_stream(const float *rec, const float *ktab, const WrnnRow *rows, float *cond, int n_rows, int T,
                                    int HOP, long total_len, long steps, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     dim3 grid((unsigned)((steps + 63) / 64), n_rows);
     hipLaunchKernelGGL(cond_stream_kernel, grid, dim3(512), 0, s, rec, ktab, rows, (float4 *)cond, T, HOP, total_len, steps);
     return hipGetLastError();

@@ -209,3 +209,26 @@ def test_philox_sampling_is_distributionally_correct():
     check_free_run_raw(got, ref)
     # and the histogram is not degenerate
     assert len(np.unique(got)) > 50
+
+
+@pytest.mark.parametrize('kernel', ['team2', 'team'])
+def test_many_rows_are_scheduled_independently(kernel):
+    """BASELINE configs[2]-style batch: 19 rows (two full waves of 8 XCD teams + a ragged tail).  Greedy sampling
+    (q == 1), rows 0..18 use 3 distinct mels in rotation: rows with the same mel must produce identical label
+    sequences whatever team / XCD / position in the row queue ran them, and row 0 must match the oracle."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels
+    fx = load_case('raw_peaky_b1_t24')
+    m = _model(fx, kernel)
+    base = make_mels(77, 3, 21)
+    mels = np.stack([base[i % 3] for i in range(19)])
+    res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_ARGMAX)
+    lab = res['labels'].cpu().numpy()
+    assert lab.shape == (19, 21 * 275)
+    for i in range(3, 19):
+        np.testing.assert_array_equal(lab[i], lab[i % 3])
+    assert not np.array_equal(lab[0], lab[1])
+    om = orc.OracleModel(fx['state_dict'], fast=True)
+    cm, ca = om.conditioning(base[:1])
+    ref = om.loop(cm, ca, orc.NOISE_ARGMAX)
+    check_free_run_raw(lab[:1].T, ref)
