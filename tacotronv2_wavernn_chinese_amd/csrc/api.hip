@@ -104,6 +104,13 @@ int wrnn_create(const wrnn_config *cfg, wrnn_handle **out) {
         return fail(h, WRNN_ERR_INVALID, "upsample edge reach %d exceeds indent %d: composite FIR not shift-invariant", reach, cfg->pad * hop);
     if (d.NC > 1024) return fail(h, WRNN_ERR_INVALID, "n_classes %d > 1024 unsupported", d.NC);
     HIP_TRY(h, hipSetDevice(cfg->device));
+    {
+        // team kernels: one team per XCD = 32 CUs (SPX: 256 CUs = 8 teams; a CPX/DPX partition exposes fewer)
+        hipDeviceProp_t prop;
+        HIP_TRY(h, hipGetDeviceProperties(&prop, cfg->device));
+        h->n_teams = prop.multiProcessorCount / 32;
+        if (h->n_teams > 8) h->n_teams = 8;
+    }
     for (int i = 0; i < 3; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
     HIP_TRY(h, hipMalloc(&h->err_dev, 64));
     HIP_TRY(h, hipMemset(h->err_dev, 0, 64));
@@ -314,7 +321,7 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
     if ((rc = upload(h->team_w, tw)) || (rc = upload(h->team_fc3, tf3)) || (rc = upload(h->wI0, vwI0)) || (rc = upload(h->u1, vu1))) return rc;
     if (!h->mail) {
         HIP_TRY(h, hipMalloc(&h->mail, (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long)));
-        HIP_TRY(h, hipMalloc(&h->ctl, 64));
+        HIP_TRY(h, hipMalloc(&h->ctl, 128));
         if (getenv("WRNN_TEAM_PROF")) { HIP_TRY(h, hipMalloc(&h->prof, 8 * 17 * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->prof, 0, 8 * 17 * sizeof(unsigned long long))); }
     }
     if (h->wdev) { (void)hipFree(h->wdev); h->wdev = nullptr; }
@@ -420,6 +427,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));
     } else if (kernel == WRNN_KERNEL_TEAM || kernel == WRNN_KERNEL_TEAM2) {
+        if (h->n_teams < 1) return fail(h, WRNN_ERR_INVALID, "team kernels need at least one full XCD (32 CUs)");
         if (d.ND != 5 || d.HOP > 275) return fail(h, WRNN_ERR_INVALID, "team kernel is built for pad=2 (5-frame upsampling support), hop <= 275");
         // conditioning pushed through the linear layers it feeds (once per call)
         const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, P = d.P;
@@ -461,12 +469,12 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             HIP_TRY(h, wrnn_launch_cond_stream(tREC, w + o.ktab, h->rows_dev, tCOND, rows, T, d.HOP, a.total_len, steps, s));
         }
         HIP_TRY(h, hipMemsetAsync(h->mail, 0, (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long), s));
-        HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 64, s));
+        HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
         HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work
         WrnnTeamArgs ta{};
         ta.w = w; ta.off = o; ta.d = d; ta.team_w = h->team_w; ta.team_fc3 = h->team_fc3; ta.wI0 = h->wI0; ta.u1 = h->u1;
         ta.tabREC = tREC; ta.tabCOND = tCOND; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
-        ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = 8; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
+        ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = h->n_teams; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
         ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced;
         ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
         ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;

@@ -226,10 +226,24 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
 
     // ---- team formation: by the XCD this workgroup actually runs on ------------
     if (tid == 0) {
+        // ctl[0..7]: arrivals per physical XCC id; ctl[8]: team slots handed out; ctl[16 + xcc]: slot + 1 of that XCC.
+        // Teams are numbered in order of first arrival, so any set of XCC ids (SPX, or a partition exposing a
+        // subset of the XCDs) maps onto team slots 0..n_teams-1.
         const unsigned x = xcc_id();
         misc_i[10] = 0;
-        misc_i[0] = (int)x;
-        misc_i[1] = (int)atomicAdd(&a.ctl[x], 1u);
+        const unsigned rank = atomicAdd(&a.ctl[x], 1u);
+        unsigned slot1 = 0;
+        if (rank == 0) {
+            slot1 = atomicAdd(&a.ctl[8], 1u) + 1u;
+            __hip_atomic_store(&a.ctl[16 + x], slot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (unsigned spins = 0; spins < 4000000u; ++spins) {
+                slot1 = __hip_atomic_load(&a.ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot1) break;
+            }
+        }
+        misc_i[0] = slot1 ? (int)slot1 - 1 : 1 << 20;   // no slot seen: treated as "not in a team" below
+        misc_i[1] = (int)rank;
     }
     __syncthreads();
     const int team = __builtin_amdgcn_readfirstlane(misc_i[0]);
@@ -679,10 +693,10 @@ hipError_t wrnn_launch_loop_team(const WrnnTeamArgs &a, hipStream_t s) {
     if (a.prof && a.d.mode == WRNN_MODE_RAW) {
         hipError_t e = hipFuncSetAttribute((const void *)loop_team_kernel<WRNN_MODE_RAW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((loop_team_kernel<WRNN_MODE_RAW, true>), dim3(256), dim3(TEAM_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_team_kernel<WRNN_MODE_RAW, true>), dim3(a.n_teams * 32), dim3(TEAM_THREADS), lds, s, a);
     } else if (a.d.mode == WRNN_MODE_RAW)
-        hipLaunchKernelGGL((loop_team_kernel<WRNN_MODE_RAW, false>), dim3(256), dim3(TEAM_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_team_kernel<WRNN_MODE_RAW, false>), dim3(a.n_teams * 32), dim3(TEAM_THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL((loop_team_kernel<WRNN_MODE_MOL, false>), dim3(256), dim3(TEAM_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_team_kernel<WRNN_MODE_MOL, false>), dim3(a.n_teams * 32), dim3(TEAM_THREADS), lds, s, a);
     return hipGetLastError();
 }

@@ -70,6 +70,22 @@ __device__ __forceinline__ void finish_n(const u64 *base, unsigned idx, unsigned
     }
 }
 
+// One exchange, one granule per thread, two staggered first looks: look A is issued right away (it catches the
+// case where every producer was early), look B `T2_STAGGER` sleeps later; A is examined when it returns, B only
+// if A came back incomplete, the bounded re-read loop only if B is incomplete too.
+#ifndef T2_STAGGER
+#define T2_STAGGER 3
+#endif
+__device__ __forceinline__ unsigned take_granule(const u64 *base, unsigned idx, unsigned tag, bool &dead, unsigned *err, unsigned code) {
+    u64 ga[1], gb[1];
+    peek_n<1>(base, idx, 1, ga);
+    __builtin_amdgcn_s_sleep(T2_STAGGER);
+    peek_n<1>(base, idx, 1, gb);
+    if (__all(tags_ok<1, 32>(ga, tag))) return (unsigned)ga[0];
+    finish_n<1, 32>(base, idx, 1, tag, gb, dead, err, code);
+    return (unsigned)gb[0];
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -208,10 +224,24 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 
     // ---- team formation: by the XCD this workgroup actually runs on ------------
     if (tid == 0) {
+        // ctl[0..7]: arrivals per physical XCC id; ctl[8]: team slots handed out; ctl[16 + xcc]: slot + 1 of that XCC.
+        // Teams are numbered in order of first arrival, so any set of XCC ids (SPX, or a partition exposing a
+        // subset of the XCDs) maps onto team slots 0..n_teams-1.
         const unsigned x = xcc_id2();
         misc_i[M_DEAD] = 0;
-        misc_i[0] = (int)x;
-        misc_i[1] = (int)atomicAdd(&a.ctl[x], 1u);
+        const unsigned rank = atomicAdd(&a.ctl[x], 1u);
+        unsigned slot1 = 0;
+        if (rank == 0) {
+            slot1 = atomicAdd(&a.ctl[8], 1u) + 1u;
+            __hip_atomic_store(&a.ctl[16 + x], slot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (unsigned spins = 0; spins < 4000000u; ++spins) {
+                slot1 = __hip_atomic_load(&a.ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot1) break;
+            }
+        }
+        misc_i[0] = slot1 ? (int)slot1 - 1 : 1 << 20;   // no slot seen: treated as "not in a team" below
+        misc_i[1] = (int)rank;
     }
     __syncthreads();
     const int team = __builtin_amdgcn_readfirstlane(misc_i[0]);
@@ -397,7 +427,6 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 const float ng = tanh_fast(gn + rg * g2n);
                 const float x3u = x2u + ((1.0f - zg) * ng + zg * h2o);
                 if (q == 0) st_granule(mail, G_X3 + par * 512 + unit, epoch, __float_as_uint(x3u));
-                __builtin_amdgcn_s_sleep(3);   // first look ~250 cycles after the publish (see loop_team.hip)
             } else {
                 // ---- S: gh1 for the next step = W_hh1 . h1' + b_hh1, published for everyone ----
                 float sr, sz, sn;
@@ -412,10 +441,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(2);
             // ---- exchange 1 (all threads, granule tid): x3 = x + h2 ; h2' = x3 - x2 ----
             {
-                u64 gq[1];
-                peek_n<1>(mail, G_X3 + par * 512 + tid, 1, gq);
-                finish_n<1, 32>(mail, G_X3 + par * 512 + tid, 1, epoch, gq, dead, a.err, 11u);
-                const float x3 = __uint_as_float((unsigned)gq[0]);
+                const float x3 = __uint_as_float(take_granule(mail, G_X3 + par * 512 + tid, epoch, dead, a.err, 11u));
                 xb[XB_X3 * 512 + pj] = x3;
                 xb[XB_H2 * 512 + pj] = x3 - x2_j;
             }
@@ -427,7 +453,6 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 // ---- phase C: fc1 row `unit` (:217-218) ----
                 const float s = row_sum(dot32(wv + 128, xb + XB_X3 * 512, q)) + cstQ[11];
                 if (q == 0) st_granule(mail, G_F1 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
-                __builtin_amdgcn_s_sleep(3);
             } else {
                 // ---- S: sampling noise of step t+1 (C reads the other parity slot this step) ----
                 if (t + 1 < a.steps) s_noise(t + 1, epoch + 1);
@@ -435,10 +460,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(5);
             // ---- exchange 2: fc1 outputs ----
             {
-                u64 gq[1];
-                peek_n<1>(mail, G_F1 + par * 512 + tid, 1, gq);
-                finish_n<1, 32>(mail, G_F1 + par * 512 + tid, 1, epoch, gq, dead, a.err, 12u);
-                xb[XB_F1 * 512 + pj] = __uint_as_float((unsigned)gq[0]);
+                xb[XB_F1 * 512 + pj] = __uint_as_float(take_granule(mail, G_F1 + par * 512 + tid, epoch, dead, a.err, 12u));
             }
             P2(6);
             __syncthreads();  // B3
@@ -448,7 +470,6 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 // ---- phase D: fc2 row `unit` (:220-221) ----
                 const float s = row_sum(dot32(wv + 96, xb + XB_F1 * 512, q)) + cstQ[12];
                 if (q == 0) st_granule(mail, G_F2 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
-                __builtin_amdgcn_s_sleep(3);
             } else {
                 // ---- S: conditioning + noise of step t+1 ----
                 if (t + 1 < a.steps) s_prepare(t + 1, epoch + 1);
@@ -456,10 +477,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(8);
             // ---- exchange 3: fc2 outputs ----
             {
-                u64 gq[1];
-                peek_n<1>(mail, G_F2 + par * 512 + tid, 1, gq);
-                finish_n<1, 32>(mail, G_F2 + par * 512 + tid, 1, epoch, gq, dead, a.err, 13u);
-                xb[XB_F2 * 512 + pj] = __uint_as_float((unsigned)gq[0]);
+                xb[XB_F2 * 512 + pj] = __uint_as_float(take_granule(mail, G_F2 + par * 512 + tid, epoch, dead, a.err, 13u));
             }
             P2(9);
             __syncthreads();  // B4
@@ -626,10 +644,10 @@ hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s) {
     if (a.prof && a.d.mode == WRNN_MODE_RAW) {
         hipError_t e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_RAW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, true>), dim3(256), dim3(T2_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, true>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
     } else if (a.d.mode == WRNN_MODE_RAW)
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, false>), dim3(256), dim3(T2_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, false>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_MOL, false>), dim3(256), dim3(T2_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_MOL, false>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
     return hipGetLastError();
 }

@@ -84,6 +84,7 @@ struct wrnn_handle {
     size_t cond_cap = 0;
     unsigned long long *mail = nullptr;
     unsigned *ctl = nullptr;
+    int n_teams = 8;              // XCDs (32-CU teams) of this device
     unsigned long long *prof = nullptr;   // set when WRNN_TEAM_PROF=1 in the environment
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
@@ -139,7 +140,7 @@ struct WrnnTeamArgs {
     const float *tabC4;       // (B, T+1, FC)   fc2.W[:,FC:] . a4[i] + b2
     const WrnnRow *rows;
     int32_t n_rows;
-    int32_t n_teams;
+    int32_t n_teams;          // teams = XCDs in use; the launch grid is n_teams * 32 workgroups
     int32_t T;
     int64_t total_len;
     int64_t steps;
