@@ -1,0 +1,136 @@
+"""Host side of the drop-in (no GPU): the reference's call surface, file formats and error behaviour."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(mode='RAW'):
+    from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+    dims = dict(DEFAULT_DIMS)
+    dims['bits'] = 10 if mode == 'RAW' else 9
+    return WaveRNN(**dims, mode=mode)
+
+
+def test_state_dict_layout_matches_the_contract(capsys):
+    m = _model()
+    assert 'Trainable Parameters: 4.744M' in capsys.readouterr().out      # num_params() print of the reference
+    sd = m.state_dict()
+    synth = make_state_dict(0)
+    assert list(sd.keys()) == list(synth.keys()) and len(sd) == 148
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(synth[k].shape), k
+    assert m.n_classes == 1024 and _model('MOL').n_classes == 30
+    assert m.get_step() == 0
+    with pytest.raises(RuntimeError):
+        from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+        WaveRNN(**DEFAULT_DIMS, mode='XYZ')
+    with pytest.raises(NotImplementedError):
+        m.forward(None, None)
+
+
+@pytest.mark.reference
+def test_state_dict_and_default_init_equal_the_reference_module():
+    from oracle import ref_harness as rh
+    ref = rh.load_reference()
+    args = (512, 512, 10, 2, (5, 5, 11), 80, 128, 128, 10, 275, 22050, 'RAW')
+    from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+    torch.manual_seed(3)
+    a = ref.fv.WaveRNN(*args)
+    torch.manual_seed(3)
+    b = WaveRNN(*args)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+def test_load_is_strict_false_and_save_round_trips(tmp_path):
+    m = _model()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in make_state_dict(5).items()}
+    partial = {k: v for k, v in sd.items() if not k.startswith('fc3')}
+    partial['not_a_key'] = torch.zeros(3)
+    p = tmp_path / 'w.pyt'
+    torch.save(partial, p)
+    before = m.fc3.weight.clone()
+    m.load(p)                                      # strict=False: missing + unexpected keys are fine
+    assert torch.equal(m.fc3.weight, before)
+    assert torch.equal(m.I.weight, sd['I.weight'])
+    m.save(p)
+    again = torch.load(p)
+    assert set(again.keys()) == set(m.state_dict().keys())
+
+
+def test_generate_refuses_to_run_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    m = _model()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.generate(np.zeros((1, 80, 21), np.float32), '/tmp/x.wav', False, 11000, 550, True)
+
+
+def test_epilogue_pieces_match_the_oracle_restatement():
+    from tacotronv2_wavernn_chinese_amd.dsp import decode_mu_law, label_2_float
+    m = _model()
+    rng = np.random.default_rng(0)
+    y = rng.uniform(-1, 1, (4, 2400))
+    np.testing.assert_array_equal(m.xfade_and_unfold(y.copy(), 2000, 200), orc.xfade_and_unfold(y.copy(), 2000, 200))
+    lab = rng.integers(0, 1024, 100).astype(np.float64)
+    f = label_2_float(lab, 10)
+    np.testing.assert_allclose(decode_mu_law(f, 1024, False), orc.decode_mu_law(f, 1024), rtol=0, atol=0)
+    np.testing.assert_allclose(decode_mu_law(lab, 1024, True), orc.decode_mu_law(f, 1024), rtol=0, atol=1e-15)
+
+
+def test_save_wav_is_a_float32_wav_at_the_sample_rate(tmp_path):
+    from scipy.io import wavfile
+    from tacotronv2_wavernn_chinese_amd.dsp import save_wav
+    x = np.linspace(-0.5, 0.5, 1000)
+    save_wav(x, tmp_path / 'a.wav', 22050)
+    sr, data = wavfile.read(tmp_path / 'a.wav')
+    assert sr == 22050 and data.dtype == np.float32
+    np.testing.assert_array_equal(data, x.astype(np.float32))
+
+
+def test_hparams_singleton_semantics(tmp_path):
+    code = ("from tacotronv2_wavernn_chinese_amd.hparams import hparams as hp\n"
+            "import sys\n"
+            "try:\n    hp.bits\n    sys.exit(3)\nexcept AttributeError:\n    pass\n"
+            "hp.configure()\n"
+            "assert (hp.bits, hp.hop_length, hp.voc_upsample_factors, hp.voc_mode, hp.voc_target, hp.voc_overlap) == (10, 275, (5, 5, 11), 'RAW', 11000, 550)\n"
+            "try:\n    hp.configure()\n    sys.exit(4)\nexcept RuntimeError:\n    pass\n")
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_gen_from_file_validates_like_the_reference(tmp_path):
+    code = (
+        "import numpy as np, sys\n"
+        "from tacotronv2_wavernn_chinese_amd.hparams import hparams as hp\n"
+        "hp.configure()\n"
+        "from tacotronv2_wavernn_chinese_amd.gen import gen_from_file\n"
+        "class M:\n"
+        "    def get_step(self): return 123456\n"
+        "    def generate(self, mel, path, batched, target, overlap, mu_law):\n"
+        "        print('CALL', tuple(mel.shape), path, batched, target, overlap, mu_law)\n"
+        f"d = r'{tmp_path}'\n"
+        "np.save(d + '/ok.npy', np.random.rand(33, 80).astype(np.float32))\n"
+        "np.save(d + '/badshape.npy', np.random.rand(33, 79).astype(np.float32))\n"
+        "np.save(d + '/badrange.npy', 2 * np.ones((33, 80), np.float32))\n"
+        "gen_from_file(M(), d + '/ok.npy', d, False, 11000, 550)\n"
+        "gen_from_file(M(), d + '/ok.npy', d, True, 2000, 200)\n"
+        "for bad in ('badshape.npy', 'badrange.npy', 'x.txt', 'x.wav'):\n"
+        "    try:\n        gen_from_file(M(), d + '/' + bad, d, False, 11000, 550)\n        sys.exit(5)\n"
+        "    except ValueError:\n        pass\n")
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    calls = [l for l in r.stdout.splitlines() if l.startswith('CALL')]
+    # (1, n_mels, T) tensor, reference file-name pattern (wavernn_gen.py:35-39), hp.mu_law
+    assert "(1, 80, 33)" in calls[0] and 'ok_gen_NOT_BATCHED_step=123k.wav' in calls[0] and calls[0].endswith('True')
+    assert 'ok_gen_batched_target2000_overlap200_step=123k.wav' in calls[1]
