@@ -365,7 +365,10 @@ int wrnn_plan(wrnn_handle *h, int32_t B, int32_t T, int32_t batched, int32_t tar
     // batch-1 x; any other batch size raises in the reference.
     if (B != 1) return fail(h, WRNN_ERR_INVALID, "batched generation requires a single utterance (fold_with_overlap)");
     if (target < 1 || overlap < 0) return fail(h, WRNN_ERR_INVALID, "bad target/overlap");
-    int64_t num_folds = (total - overlap) / ((int64_t)target + overlap);
+    // Python floor division like fatchord_version.py:319 (a clip shorter than `overlap` gives -1 -> 0 folds -> error)
+    const int64_t fold_den = (int64_t)target + overlap, fold_num = total - overlap;
+    int64_t num_folds = fold_num / fold_den;
+    if (fold_num % fold_den != 0 && fold_num < 0) --num_folds;
     const int64_t extended = num_folds * ((int64_t)overlap + target) + overlap;
     if (total - extended != 0) num_folds += 1;
     if (num_folds < 1) return fail(h, WRNN_ERR_INVALID, "sequence shorter than one fold");

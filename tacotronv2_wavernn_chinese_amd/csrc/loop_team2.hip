@@ -581,21 +581,25 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                     }
                 }
             } else {
-                // ---- S, window B4-B5: per-frame constants for the C quarter, then the gh1 gather (6 granules / thread) ----
+                // ---- S, window B4-B5 (S has ~1000 cycles of slack here): per-frame constants for the C quarter; HBM
+                // prefetch of the conditioning two steps ahead, issued FIRST so that its ~1 us latency elapses under
+                // gh2's ALU work and only the (slack-rich) gh1 gather queues behind it; gh2; the gh1 gather ----
                 s_frame_consts();
+                s_prefetch(t + 2);
+                {
+                    // gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter (C read the
+                    // old value back in phase B, three barriers ago)
+                    float sr, sz, sn;
+                    dot32x3_mixed(wv + 96, swl, xb + XB_H2 * 512, q, sr, sz, sn);
+                    sr = row_sum(sr) + cstQ[3]; sz = row_sum(sz) + cstQ[4]; sn = row_sum(sn) + cstQ[5];
+                    if (q == 0) { hand[0] = sr; hand[1] = sz; hand[2] = sn; }
+                }
+                P2(13);
                 u64 gq[6];
                 peek_n<6>(mail, G_GH + par * 1536 + sidx, 256, gq);
                 finish_n<6, 32>(mail, G_GH + par * 1536 + sidx, 256, epoch, gq, dead, a.err, 15u);
 #pragma unroll
                 for (int m = 0; m < 6; ++m) gh1s[sidx + m * 256] = __uint_as_float((unsigned)gq[m]);
-                P2(13);
-                s_prefetch(t + 2);   // lands during gh2 and the next step's windows 1-3
-                // gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter (C read the old
-                // value back in phase B, two barriers ago)
-                float sr, sz, sn;
-                dot32x3_mixed(wv + 96, swl, xb + XB_H2 * 512, q, sr, sz, sn);
-                sr = row_sum(sr) + cstQ[3]; sz = row_sum(sz) + cstQ[4]; sn = row_sum(sn) + cstQ[5];
-                if (q == 0) { hand[0] = sr; hand[1] = sz; hand[2] = sn; }
             }
             P2(11);
             __syncthreads();  // B5

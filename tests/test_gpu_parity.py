@@ -260,3 +260,38 @@ def test_cli_and_gen_from_file_end_to_end(tmp_path):
                         '-t', '2000', '-o', '200'], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / 'wavernn_inference_output' / 'mel-000_gen_batched_target2000_overlap200_step=0k.wav').exists()
+
+
+def test_edge_shapes_and_bad_arguments():
+    """Smallest clips, frame-boundary lengths and invalid arguments through the C-ABI (no crash, loud errors)."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels
+    fx = load_case('raw_peaky_b1_t24')
+    om = orc.OracleModel(fx['state_dict'], fast=True)
+    for kernel in ('team2', 'team'):
+        m = _model(fx, kernel)
+        for T in (1, 2, 5):                      # shorter than the 5-frame upsampling support / the fade-out
+            mels = make_mels(100 + T, 1, T)
+            res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_ARGMAX)
+            lab = res['labels'].cpu().numpy()
+            assert lab.shape == (1, T * 275)
+            cm, ca = om.conditioning(mels)
+            check_free_run_raw(lab.T, om.loop(cm, ca, orc.NOISE_ARGMAX))
+        # folded mode whose last fold is mostly zero padding ('after' padding of fold_with_overlap)
+        mels = make_mels(9, 1, 9)
+        res = m.generate_raw(mels, True, 1000, 100, noise_mode=_cabi.NOISE_ARGMAX)
+        cm, ca = om.conditioning(mels)
+        fm, fa = om.fold(cm, 1000, 100), om.fold(ca, 1000, 100)
+        assert res['labels'].shape == (fm.shape[0], 1200)
+        check_free_run_raw(res['labels'].cpu().numpy().T, om.loop(fm, fa, orc.NOISE_ARGMAX))
+    nat = m.native()
+    with pytest.raises(_cabi.WrnnError):
+        nat.plan(0, 10, False, 11000, 550)
+    with pytest.raises(_cabi.WrnnError):
+        nat.plan(1, 0, False, 11000, 550)
+    with pytest.raises(_cabi.WrnnError):        # a sequence shorter than one fold
+        nat.plan(1, 1, True, 11000, 550)
+    with pytest.raises(ValueError):
+        m.generate_raw(np.zeros((80, 30), np.float32), False, 11000, 550)
+    with pytest.raises(_cabi.WrnnError):        # injected mode without noise pointers
+        m.generate_raw(make_mels(1, 1, 3), False, 11000, 550, noise_mode=_cabi.NOISE_INJECTED)
