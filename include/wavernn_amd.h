@@ -157,6 +157,19 @@ const char *wrnn_last_error(const wrnn_handle *h);
 int32_t wrnn_abi_version(void);
 void wrnn_destroy(wrnn_handle *h);
 
+/* ---- secondary model: wavernn/models/deepmind_version.py (unconditioned dual-softmax coarse/fine WaveRNN; no
+ * reference script imports it).  Entry points mirror WaveRNN(hidden_size, quantisation) :9-31, load_state_dict and
+ * generate(seq_len) :75-165.  noise_dev (WRNN_NOISE_INJECTED): Exp(1) draws (seq_len, 2, quantisation), [t][0] for the
+ * coarse Categorical.sample() (:131), [t][1] for the fine one (:151).  Outputs: int32 (seq_len,) each; the signal is
+ * coarse * 256 + fine - 2**15 (wavernn/utils/dsp.py:33-34), combined on the host side of the binding. */
+typedef struct wrnn_dm_handle wrnn_dm_handle;
+int wrnn_dm_create(int32_t hidden_size, int32_t quantisation, int32_t device, wrnn_dm_handle **out);
+int wrnn_dm_load_weights(wrnn_dm_handle *h, const wrnn_tensor_desc *tensors, int32_t n);
+int wrnn_dm_generate(wrnn_dm_handle *h, int64_t seq_len, int32_t noise_mode, uint64_t seed, const float *noise_dev,
+                     int32_t *coarse_out_dev, int32_t *fine_out_dev, void *stream);
+const char *wrnn_dm_last_error(const wrnn_dm_handle *h);
+void wrnn_dm_destroy(wrnn_dm_handle *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,3 +40,15 @@ def noise_checksum(noise: dict) -> np.ndarray:
         a = noise[k]
         parts += [a.reshape(-1)[:8].astype(np.float64), [a.astype(np.float64).sum()]]
     return np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1) for p in parts])
+
+
+def dm_noise_from_seed(seed: int, steps: int, quant: int = 256) -> np.ndarray:
+    """deepmind_version.generate() (:75-165) draws two Categorical samples per step (coarse :131, fine :151), each an
+    ``empty(1, quant).exponential_(1)`` inside torch.multinomial; nothing else touches the generator."""
+    import torch
+    torch.manual_seed(seed)
+    out = torch.empty(steps, 2, quant)
+    for t in range(steps):
+        out[t, 0] = torch.empty(1, quant).exponential_(1)[0]
+        out[t, 1] = torch.empty(1, quant).exponential_(1)[0]
+    return out.numpy()

@@ -218,6 +218,46 @@ class OracleModel:
         return int(self.lib.wo_num_threads())
 
 
+class _DmModel(C.Structure):
+    _fields_ = [('hidden', C.c_int), ('quant', C.c_int)] + \
+               [(n, _FP) for n in ('R', 'O1w', 'O1b', 'O2w', 'O2b', 'O3w', 'O3b', 'O4w', 'O4b', 'Ic', 'If', 'bu', 'br', 'be')]
+
+
+class DeepmindOracle:
+    """C restatement of ``wavernn/models/deepmind_version.py`` generate() (rows A12 of SURVEY.md section 8a)."""
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], fast: bool = False):
+        self.lib = _lib(fast)
+        self.lib.wo_dm_generate.restype = C.c_int
+        self._keep = []
+        m = _DmModel()
+        m.hidden = state_dict['R.weight'].shape[1]
+        m.quant = state_dict['O2.weight'].shape[0]
+        for f, k in (('R', 'R.weight'), ('O1w', 'O1.weight'), ('O1b', 'O1.bias'), ('O2w', 'O2.weight'), ('O2b', 'O2.bias'),
+                     ('O3w', 'O3.weight'), ('O3b', 'O3.bias'), ('O4w', 'O4.weight'), ('O4b', 'O4.bias'),
+                     ('Ic', 'I_coarse.weight'), ('If', 'I_fine.weight'), ('bu', 'bias_u'), ('br', 'bias_r'), ('be', 'bias_e')):
+            arr = np.ascontiguousarray(state_dict[k], dtype=np.float32)
+            self._keep.append(arr)
+            setattr(m, f, _p(arr))
+        self.m = m
+        self.quant = m.quant
+
+    def generate(self, seq_len: int, noise: Optional[np.ndarray] = None) -> dict:
+        """noise: (seq_len, 2, Q) Exp(1) draws (coarse, fine) or None for greedy."""
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, dtype=np.float32)
+            assert noise.shape == (seq_len, 2, self.quant)
+        coarse = np.empty(seq_len, np.int32)
+        fine = np.empty(seq_len, np.int32)
+        margin = np.empty((seq_len, 2), np.float32)
+        runner = np.empty((seq_len, 2), np.int32)
+        rc = self.lib.wo_dm_generate(C.byref(self.m), C.c_long(seq_len), _p(noise), _p(coarse, C.c_int32), _p(fine, C.c_int32),
+                                     _p(margin), _p(runner, C.c_int32))
+        assert rc == 0
+        # combine_signal, wavernn/utils/dsp.py:33-34
+        return dict(coarse=coarse, fine=fine, output=coarse * 256 + fine - 2 ** 15, margin=margin, runner=runner)
+
+
 # -------------------------------------------------------------- epilogue (f64)
 
 def decode_mu_law(y: np.ndarray, mu: int) -> np.ndarray:

@@ -171,3 +171,19 @@ def reference_upsample(model, mels: np.ndarray):
         up, aux = model.upsample(m.transpose(1, 2))
     model.train()
     return up.numpy(), aux.numpy()
+
+
+def reference_dm_generate(state_dict: Dict[str, np.ndarray], seq_len: int, seed: int) -> dict:
+    """Run the reference's ``deepmind_version.WaveRNN.generate(seq_len)`` (:75-165).  Upstream it cannot run as
+    shipped: it calls ``stream(fmt, args)`` with two arguments (:159) while ``display.stream`` takes one -- that
+    progress print is replaced by a no-op (non-semantic); everything else is the unmodified reference."""
+    import torch
+    load_reference()
+    import wavernn.models.deepmind_version as dm
+    dm.stream = lambda *a, **k: None
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = dm.WaveRNN(hidden_size=state_dict['R.weight'].shape[1], quantisation=state_dict['O2.weight'].shape[0])
+    model.load_state_dict({k: torch.from_numpy(np.array(v, copy=True)) for k, v in state_dict.items()}, strict=True)
+    torch.manual_seed(seed)
+    output, coarse, fine = model.generate(seq_len)
+    return dict(output=np.asarray(output), coarse=np.asarray(coarse), fine=np.asarray(fine))

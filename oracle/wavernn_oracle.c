@@ -396,3 +396,89 @@ void wo_set_num_threads(int n) {
     (void)n;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * A12 (secondary): wavernn/models/deepmind_version.py -- unconditioned dual-softmax (coarse/fine)
+ * WaveRNN, generate(seq_len) :75-165.  Weights row-major as in its state_dict:
+ *   R (3H, H) no bias :16 | O1 (S,S)+b, O2 (Q,S)+b, O3 (S,S)+b, O4 (Q,S)+b :19-22 |
+ *   I_coarse (3S, 2) :25, I_fine (3S, 3) :26 | bias_u, bias_r, bias_e (H) :29-31;  S = H/2.
+ * noise: q (seq_len, 2, Q) Exp(1) draws -- [t][0] for the coarse Categorical.sample(), [t][1] for the fine one
+ * (torch.multinomial n=1 == argmax(p/q)); NULL = greedy.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int hidden;  /* 896 */
+    int quant;   /* 256 */
+    const float *R, *O1w, *O1b, *O2w, *O2b, *O3w, *O3b, *O4w, *O4b, *Ic, *If, *bu, *br, *be;
+} wo_dm_model;
+
+static int dm_sample(const float *logits, int Q, const float *q, float *p, float *margin, int32_t *runner) {
+    float mx = logits[0];
+    for (int k = 1; k < Q; ++k) mx = logits[k] > mx ? logits[k] : mx;
+    float sum = 0.0f;
+    for (int k = 0; k < Q; ++k) { p[k] = expf(logits[k] - mx); sum += p[k]; }   /* F.softmax :129,:149 */
+    float sum2 = 0.0f;
+    for (int k = 0; k < Q; ++k) { p[k] = p[k] / sum; sum2 += p[k]; }            /* Categorical renormalises */
+    float best = -1.0f, second = -1.0f;
+    int bi = 0, si = -1;
+    for (int k = 0; k < Q; ++k) {
+        float v = p[k] / sum2;
+        if (q) v = v / q[k];
+        if (v > best) { second = best; si = bi; best = v; bi = k; }
+        else if (v > second) { second = v; si = k; }
+    }
+    if (margin) *margin = best > 0.0f ? (best - second) / best : 0.0f;
+    if (runner) *runner = si;
+    return bi;
+}
+
+int wo_dm_generate(const wo_dm_model *m, long seq_len, const float *noise, int32_t *coarse, int32_t *fine,
+                   float *margin_out /* (seq_len,2) or NULL */, int32_t *runner_out /* (seq_len,2) or NULL */) {
+    const int H = m->hidden, S = H / 2, Q = m->quant;
+    float *h = (float *)calloc((size_t)H, sizeof(float));          /* get_initial_hidden :168-170 */
+    float *Rh = (float *)malloc((size_t)3 * H * sizeof(float));
+    float *t1 = (float *)malloc((size_t)S * sizeof(float));
+    float *lg = (float *)malloc((size_t)Q * sizeof(float));
+    float *p = (float *)malloc((size_t)Q * sizeof(float));
+    float *zero = (float *)calloc((size_t)3 * H, sizeof(float));
+    if (!h || !Rh || !t1 || !lg || !p || !zero) return -1;
+    int oc = 0, of = 0;                                             /* out_coarse = out_fine = 0 :90-91 */
+    for (long t = 0; t < seq_len; ++t) {
+        const float pc = (float)oc / 127.5f - 1.0f, pf = (float)of / 127.5f - 1.0f;   /* :106-107 */
+        matvec(m->R, zero, h, Rh, 3 * H, H);                        /* R(hidden), split 6 ways :116-119 */
+        /* coarse gates :111-125 ; R_hidden layout: [u_c | u_f | r_c | r_f | e_c | e_f] */
+        for (int j = 0; j < S; ++j) {
+            const float Iu = m->Ic[(size_t)j * 2] * pc + m->Ic[(size_t)j * 2 + 1] * pf;
+            const float Ir = m->Ic[(size_t)(S + j) * 2] * pc + m->Ic[(size_t)(S + j) * 2 + 1] * pf;
+            const float Ie = m->Ic[(size_t)(2 * S + j) * 2] * pc + m->Ic[(size_t)(2 * S + j) * 2 + 1] * pf;
+            const float u = sigmoidf_(Rh[j] + Iu + m->bu[j]);
+            const float r = sigmoidf_(Rh[H + j] + Ir + m->br[j]);
+            const float e = tanhf(r * Rh[2 * H + j] + Ie + m->be[j]);
+            h[j] = u * h[j] + (1.0f - u) * e;
+        }
+        matvec(m->O1w, m->O1b, h, t1, S, S);                        /* O2(relu(O1(hidden_coarse))) :128 */
+        for (int j = 0; j < S; ++j) t1[j] = t1[j] > 0.0f ? t1[j] : 0.0f;
+        matvec(m->O2w, m->O2b, t1, lg, Q, S);
+        oc = dm_sample(lg, Q, noise ? noise + ((size_t)t * 2 + 0) * Q : NULL, p, margin_out ? margin_out + t * 2 : NULL,
+                       runner_out ? runner_out + t * 2 : NULL);
+        coarse[t] = oc;
+        const float cp = (float)oc / 127.5f - 1.0f;                 /* :135 */
+        for (int j = 0; j < S; ++j) {                               /* fine gates :136-145 */
+            const float *wu = m->If + (size_t)j * 3, *wr = m->If + (size_t)(S + j) * 3, *we = m->If + (size_t)(2 * S + j) * 3;
+            const float Iu = wu[0] * pc + wu[1] * pf + wu[2] * cp;
+            const float Ir = wr[0] * pc + wr[1] * pf + wr[2] * cp;
+            const float Ie = we[0] * pc + we[1] * pf + we[2] * cp;
+            const float u = sigmoidf_(Rh[S + j] + Iu + m->bu[S + j]);
+            const float r = sigmoidf_(Rh[H + S + j] + Ir + m->br[S + j]);
+            const float e = tanhf(r * Rh[2 * H + S + j] + Ie + m->be[S + j]);
+            h[S + j] = u * h[S + j] + (1.0f - u) * e;
+        }
+        matvec(m->O3w, m->O3b, h + S, t1, S, S);                    /* O4(relu(O3(hidden_fine))) :148 */
+        for (int j = 0; j < S; ++j) t1[j] = t1[j] > 0.0f ? t1[j] : 0.0f;
+        matvec(m->O4w, m->O4b, t1, lg, Q, S);
+        of = dm_sample(lg, Q, noise ? noise + ((size_t)t * 2 + 1) * Q : NULL, p, margin_out ? margin_out + t * 2 + 1 : NULL,
+                       runner_out ? runner_out + t * 2 + 1 : NULL);
+        fine[t] = of;
+    }
+    free(h); free(Rh); free(t1); free(lg); free(p); free(zero);
+    return 0;
+}

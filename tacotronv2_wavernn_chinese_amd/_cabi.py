@@ -26,7 +26,8 @@ ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN
 # every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
-                    'wrnn_abi_version', 'wrnn_destroy')
+                    'wrnn_abi_version', 'wrnn_destroy',
+                    'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy')
 
 
 class WrnnError(RuntimeError):
@@ -118,6 +119,16 @@ def load_library() -> C.CDLL:
     lib.wrnn_abi_version.restype = C.c_int32
     lib.wrnn_destroy.argtypes = [vp]
     lib.wrnn_destroy.restype = None
+    lib.wrnn_dm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.wrnn_dm_create.restype = C.c_int
+    lib.wrnn_dm_load_weights.argtypes = [vp, C.POINTER(TensorDesc), C.c_int32]
+    lib.wrnn_dm_load_weights.restype = C.c_int
+    lib.wrnn_dm_generate.argtypes = [vp, C.c_int64, C.c_int32, C.c_uint64, vp, vp, vp, vp]
+    lib.wrnn_dm_generate.restype = C.c_int
+    lib.wrnn_dm_last_error.argtypes = [vp]
+    lib.wrnn_dm_last_error.restype = C.c_char_p
+    lib.wrnn_dm_destroy.argtypes = [vp]
+    lib.wrnn_dm_destroy.restype = None
     _lib = lib
     return lib
 
@@ -217,3 +228,58 @@ class NativeVocoder:
         t = Timing()
         self._check(self.lib.wrnn_last_timing(self._h, C.byref(t)))
         return dict(prologue_ms=t.prologue_ms, loop_ms=t.loop_ms, kernel=t.kernel, rows=t.rows, steps=t.steps)
+
+
+def _tensor_descs(state_dict: Dict[str, np.ndarray]):
+    keep, descs = [], []
+    for name, arr in state_dict.items():
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype != np.float32 or arr.ndim > 4:
+            continue
+        d = TensorDesc()
+        d.name = name.encode()
+        d.dtype, d.ndim = DTYPE_F32, arr.ndim
+        for i, sdim in enumerate(arr.shape):
+            d.shape[i] = sdim
+        d.data = arr.ctypes.data
+        keep.append(arr)
+        descs.append(d)
+    return keep, (TensorDesc * len(descs))(*descs), len(descs)
+
+
+class NativeDeepmind:
+    """Owner of one ``wrnn_dm_handle`` (the secondary dual-softmax model)."""
+
+    def __init__(self, hidden_size: int, quantisation: int, device: int):
+        self.lib = load_library()
+        self.device = int(device)
+        self._h = C.c_void_p()
+        rc = self.lib.wrnn_dm_create(hidden_size, quantisation, device, C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.wrnn_dm_last_error(self._h).decode() if self._h else 'wrnn_dm_create failed'
+            self.close()
+            raise WrnnError(rc, msg)
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise WrnnError(rc, self.lib.wrnn_dm_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.wrnn_dm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, state_dict: Dict[str, np.ndarray]):
+        keep, arr, n = _tensor_descs(state_dict)
+        self._check(self.lib.wrnn_dm_load_weights(self._h, arr, n))
+
+    def generate(self, seq_len: int, coarse_ptr: int, fine_ptr: int, stream: int, noise_mode: int = NOISE_PHILOX,
+                 seed: int = 0, noise_ptr: int = 0):
+        self._check(self.lib.wrnn_dm_generate(self._h, int(seq_len), noise_mode, seed & 0xFFFFFFFFFFFFFFFF,
+                                              noise_ptr or None, coarse_ptr, fine_ptr, stream or None))

@@ -108,3 +108,28 @@ def make_mels(seed: int, batch: int, frames: int, feat_dims: int = 80) -> np.nda
     """(B, 80, T) float32 in [0,1) -- satisfies wavernn_gen.py:25-28."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.random((batch, feat_dims, frames), dtype=np.float32)
+
+
+def make_dm_state_dict(seed: int = 0, hidden_size: int = 896, quantisation: int = 256,
+                       out_scale: float = 16.0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded synthetic state_dict of the unconditioned dual-softmax model
+    (``wavernn/models/deepmind_version.py:10-31``).  ``out_scale`` sharpens the two softmaxes (O2/O4) and the gate
+    biases are randomised (the reference initialises them to zero) so every term of the step is exercised."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    H, S, Q = hidden_size, hidden_size // 2, quantisation
+
+    def uni(shape, fan_in):
+        k = 1.0 / np.sqrt(fan_in)
+        return rng.uniform(-k, k, size=shape).astype(np.float32)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    sd['bias_u'] = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    sd['bias_r'] = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    sd['bias_e'] = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    sd['R.weight'] = uni((3 * H, H), H)
+    sd['O1.weight'] = uni((S, S), S); sd['O1.bias'] = uni((S,), S)
+    sd['O2.weight'] = (uni((Q, S), S) * out_scale).astype(np.float32); sd['O2.bias'] = uni((Q,), S)
+    sd['O3.weight'] = uni((S, S), S); sd['O3.bias'] = uni((S,), S)
+    sd['O4.weight'] = (uni((Q, S), S) * out_scale).astype(np.float32); sd['O4.bias'] = uni((Q,), S)
+    sd['I_coarse.weight'] = uni((3 * S, 2), 2)
+    sd['I_fine.weight'] = uni((3 * S, 3), 3)
+    return sd
