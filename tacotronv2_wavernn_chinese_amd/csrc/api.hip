@@ -130,6 +130,7 @@ void wrnn_destroy(wrnn_handle *h) {
     if (h->u1) (void)hipFree(h->u1);
     if (h->tab) (void)hipFree(h->tab);
     if (h->cond) (void)hipFree(h->cond);
+    if (h->team_state) (void)hipFree(h->team_state);
     if (h->mail) (void)hipFree(h->mail);
     if (h->ctl) (void)hipFree(h->ctl);
     for (int i = 0; i < 3; ++i)
@@ -423,9 +424,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     a.samples_out = samples_out_dev; a.err = h->err_dev;
     int kernel = opts->kernel;
     if (kernel == WRNN_KERNEL_AUTO) {
-        // the wave-specialised kernel streams 8 KB of conditioning per step from HBM; keep that stream under the cap
-        const size_t cond_bytes = (size_t)rows * (size_t)steps * d.H * 4 * sizeof(float);
-        kernel = cond_bytes <= ((size_t)96 << 30) ? WRNN_KERNEL_TEAM2 : WRNN_KERNEL_TEAM;
+        kernel = WRNN_KERNEL_TEAM2;
     }
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));
@@ -441,7 +440,6 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         const size_t need = nCM + nCA + nVM + nVA + nC2 + nC3 + nC4 + nREC;
         if (need > h->tab_cap) {
             if (h->tab) (void)hipFree(h->tab);
-    if (h->cond) (void)hipFree(h->cond);
             h->tab = nullptr; h->tab_cap = 0;
             HIP_TRY(h, hipMalloc(&h->tab, need * sizeof(float)));
             h->tab_cap = need;
@@ -457,32 +455,58 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 2 * A, (size_t)T * R, R, T, w + o.fc1_t + (size_t)H * FC, FC, w + o.fc1_b, tC3, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 3 * A, (size_t)T * R, R, T, w + o.fc2_t + (size_t)FC * FC, FC, w + o.fc2_b, tC4, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         HIP_TRY(h, wrnn_launch_pack_records(tCM, tCA, tVM, tVA, tREC, B, T, P, s));
-        float *tCOND = nullptr;
+        WrnnTeamArgs ta{};
+        ta.w = w; ta.off = o; ta.d = d; ta.team_w = h->team_w; ta.team_fc3 = h->team_fc3; ta.wI0 = h->wI0; ta.u1 = h->u1;
+        ta.tabREC = tREC; ta.tabCOND = nullptr; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
+        ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = h->n_teams; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
+        ta.seg0 = 0; ta.seg_len = steps; ta.state = nullptr;
+        ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced;
+        ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
+        ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;
+        const size_t mail_bytes = (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long);
         if (kernel == WRNN_KERNEL_TEAM2) {
-            const size_t nCOND = (size_t)rows * (size_t)steps * H * 4;
-            if (nCOND * sizeof(float) > ((size_t)96 << 30))
-                return fail(h, WRNN_ERR_INVALID, "conditioning stream of %zu GB exceeds the 96 GB cap: split the batch", (nCOND * 4) >> 30);
+            // The phase-A conditioning is streamed from HBM (8 KB per row and step).  A row is generated in segments,
+            // one stream chunk + one loop launch each, sized so that the chunk (~64 MB over all rows) is still resident
+            // in the memory-side cache when the loop reads it: against a stream written once for the whole clip
+            // (903 MB for 5 s of audio, read back from DRAM) this is 6.5 % faster at B=1, bounds the scratch to
+            // rows x seg x 8 KB, and costs one relaunch (~40 us) per segment.  Segment lengths are multiples of 32
+            // steps (the shadow waves regenerate their Philox state on those boundaries).
+            int64_t seg = ((int64_t)(64u << 20) / ((int64_t)rows * H * 4 * (int64_t)sizeof(float))) & ~(int64_t)31;
+            if (seg > 16384) seg = 16384;
+            if (seg < 2048) seg = 2048;
+            if (const char *e = getenv("WRNN_TEAM2_SEGMENT")) { seg = atoll(e) & ~(int64_t)31; if (seg < 32) seg = 32; }   // developer knob
+            if (seg > steps) seg = steps;
+            const size_t nCOND = (size_t)rows * (size_t)seg * H * 4;
             if (nCOND > h->cond_cap) {
                 if (h->cond) (void)hipFree(h->cond);
                 h->cond = nullptr; h->cond_cap = 0;
                 HIP_TRY(h, hipMalloc(&h->cond, nCOND * sizeof(float)));
                 h->cond_cap = nCOND;
             }
-            tCOND = h->cond;
-            HIP_TRY(h, wrnn_launch_cond_stream(tREC, w + o.ktab, h->rows_dev, tCOND, rows, T, d.HOP, a.total_len, steps, s));
+            const size_t nST = (size_t)rows * WRNN_TEAM_STATE_FLOATS;
+            if (nST > h->team_state_cap) {
+                if (h->team_state) (void)hipFree(h->team_state);
+                h->team_state = nullptr; h->team_state_cap = 0;
+                HIP_TRY(h, hipMalloc(&h->team_state, nST * sizeof(float)));
+                h->team_state_cap = nST;
+            }
+            HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work; the stream chunks are timed with the loop
+            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * 17 * sizeof(unsigned long long), s));
+            ta.team_w = h->team_w; ta.tabCOND = h->cond; ta.state = h->team_state;
+            for (int64_t t0 = 0; t0 < steps; t0 += seg) {
+                const int64_t len = steps - t0 < seg ? steps - t0 : seg;
+                HIP_TRY(h, wrnn_launch_cond_stream(tREC, w + o.ktab, h->rows_dev, h->cond, rows, T, d.HOP, a.total_len, t0, len, s));
+                HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
+                HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
+                ta.seg0 = t0; ta.seg_len = len;
+                HIP_TRY(h, wrnn_launch_loop_team2(ta, s));
+            }
+        } else {
+            HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
+            HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
+            HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work
+            HIP_TRY(h, wrnn_launch_loop_team(ta, s));
         }
-        HIP_TRY(h, hipMemsetAsync(h->mail, 0, (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long), s));
-        HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
-        HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work
-        WrnnTeamArgs ta{};
-        ta.w = w; ta.off = o; ta.d = d; ta.team_w = h->team_w; ta.team_fc3 = h->team_fc3; ta.wI0 = h->wI0; ta.u1 = h->u1;
-        ta.tabREC = tREC; ta.tabCOND = tCOND; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
-        ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = h->n_teams; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
-        ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced;
-        ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
-        ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;
-        if (kernel == WRNN_KERNEL_TEAM2) HIP_TRY(h, wrnn_launch_loop_team2(ta, s));
-        else HIP_TRY(h, wrnn_launch_loop_team(ta, s));
     } else {
         return fail(h, WRNN_ERR_INVALID, "kernel %d not available", kernel);
     }

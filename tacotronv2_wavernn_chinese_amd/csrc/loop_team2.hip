@@ -301,22 +301,27 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 
     for (int row = team; row < a.n_rows; row += a.n_teams) {
         const WrnnRow rw = a.rows[row];
-        const float4 *CONDg = (const float4 *)a.tabCOND + (size_t)row * a.steps * 512;
+        const int64_t seg_end = a.seg0 + a.seg_len;   // this launch runs steps [seg0, seg_end) of every row
+        const bool resume = a.seg0 > 0;
+        float *st = a.state + (size_t)row * WRNN_TEAM_STATE_FLOATS;   // [h1 | h2 | gh1 | gh2 | x]
+        const float4 *CONDg = (const float4 *)a.tabCOND + ((size_t)row * a.seg_len - (size_t)a.seg0) * 512;
         const float *C2g = a.tabC2 + (size_t)rw.utt * (T + 1) * 1536;
         const float *C3g = a.tabC3 + (size_t)rw.utt * (T + 1) * 512;
         const float *C4g = a.tabC4 + (size_t)rw.utt * (T + 1) * 512;
 
-        // h1 = h2 = 0, x = 0  (:194-196)  => gh1 = b_hh1, gh2 = b_hh2
-        float h1_j = 0.0f;
-        xb[XB_H2 * 512 + pj] = 0.0f;
-        for (int i = tid; i < 1536; i += T2_THREADS) gh1s[i] = a.w[a.off.r1_bhh + i];
-        if (tid == 0) misc_f[M_XF] = 0.0f;
+        // first segment: h1 = h2 = 0, x = 0  (:194-196)  => gh1 = b_hh1, gh2 = b_hh2; later segments: the state the
+        // previous launch left in `st`
+        float h1_j = resume ? st[tid] : 0.0f;
+        float xfeed = resume ? st[4096] : 0.0f;   // x_{t-1} (:196)
+        xb[XB_H2 * 512 + pj] = resume ? st[512 + tid] : 0.0f;
+        for (int i = tid; i < 1536; i += T2_THREADS) gh1s[i] = resume ? st[1024 + i] : a.w[a.off.r1_bhh + i];
+        if (tid == 0) misc_f[M_XF] = xfeed;
         // frame of the step being prepared, tracked incrementally by the S waves (for the per-frame C constants)
-        int nfi = (int)(rw.start / HOP), nph = (int)(rw.start - (int64_t)nfi * HOP);
+        const int64_t pos0 = rw.start + a.seg0;
+        int nfi = (int)(pos0 / HOP), nph = (int)(pos0 - (int64_t)nfi * HOP);
         int cst_frame = -1000000;   // frame whose c2/c3/c4 are in the C constants
         int pend_frame = -1;        // frame whose constants must be written in the next B4-B5 window
         float nzE0 = 0.f, nzE1 = 0.f, nzn0 = 0.f, nzn1 = 0.f;   // this lane's Philox block: draws for an even / odd step
-        float xfeed = 0.0f;   // x_{t-1} (:196)
         float4 cnext0 = make_float4(0.f, 0.f, 0.f, 0.f), cnext1 = cnext0;   // conditioning prefetched two steps ahead
 
         // S: everything of step ts that does not depend on x_{ts-1}: its conditioning (prefetched from the HBM
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         // S: HBM prefetch of the conditioning of step ts (consumed by s_prepare(ts) one step later).  Issued right
         // before a stretch of ALU work so that no exchange poll queues behind these ~1 us loads.
         auto s_prefetch = [&](int64_t ts) {
-            if (ts < a.steps) {
+            if (ts < seg_end) {
                 cnext0 = CONDg[(size_t)ts * 512 + sidx];
                 cnext1 = CONDg[(size_t)ts * 512 + sidx + 256];
             }
@@ -379,16 +384,20 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             }
         };
         if (!isC) {
-            if (q == 0) { hand[0] = cstQ[3]; hand[1] = cstQ[4]; hand[2] = cstQ[5]; }   // gh2 = b_hh2
-            s_prefetch(0);
-            s_prepare(0, epoch + 1);
-            s_prefetch(1);
-            s_noise(0, epoch + 1);
+            if (q == 0) {   // gh2 = b_hh2, or carried over
+                hand[0] = resume ? st[2560 + unit] : cstQ[3];
+                hand[1] = resume ? st[2560 + 512 + unit] : cstQ[4];
+                hand[2] = resume ? st[2560 + 1024 + unit] : cstQ[5];
+            }
+            s_prefetch(a.seg0);
+            s_prepare(a.seg0, epoch + 1);
+            s_prefetch(a.seg0 + 1);
+            s_noise(a.seg0, epoch + 1);
             s_frame_consts();
         }
         __syncthreads();
 
-        for (int64_t t = 0; t < a.steps; ++t) {
+        for (int64_t t = a.seg0; t < seg_end; ++t) {
             ++epoch;
             const unsigned par = epoch & 1u;
             if (PROF) prof_last = __builtin_readcyclecounter();
@@ -430,6 +439,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             } else {
                 // ---- S: gh1 for the next step = W_hh1 . h1' + b_hh1, published for everyone ----
                 float sr, sz, sn;
+                __builtin_amdgcn_s_sleep(2);   // let the critical waves' x2 reads go first
                 dot32x3(wv, xb + XB_H1 * 512, q, sr, sz, sn);
                 sr = row_sum(sr) + cstQ[0]; sz = row_sum(sz) + cstQ[1]; sn = row_sum(sn) + cstQ[2];
                 if (q == 0) {
@@ -455,7 +465,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 if (q == 0) st_granule(mail, G_F1 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
             } else {
                 // ---- S: sampling noise of step t+1 (C reads the other parity slot this step) ----
-                if (t + 1 < a.steps) s_noise(t + 1, epoch + 1);
+                if (t + 1 < seg_end) s_noise(t + 1, epoch + 1);
             }
             P2(5);
             // ---- exchange 2: fc1 outputs ----
@@ -472,7 +482,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 if (q == 0) st_granule(mail, G_F2 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
             } else {
                 // ---- S: conditioning + noise of step t+1 ----
-                if (t + 1 < a.steps) s_prepare(t + 1, epoch + 1);
+                if (t + 1 < seg_end) s_prepare(t + 1, epoch + 1);
             }
             P2(8);
             // ---- exchange 3: fc2 outputs ----
@@ -581,11 +591,18 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                     }
                 }
             } else {
-                // ---- S, window B4-B5 (S has ~1000 cycles of slack here): per-frame constants for the C quarter; HBM
-                // prefetch of the conditioning two steps ahead, issued FIRST so that its ~1 us latency elapses under
-                // gh2's ALU work and only the (slack-rich) gh1 gather queues behind it; gh2; the gh1 gather ----
+                // ---- S, window B4-B5: per-frame constants for the C quarter; HBM prefetch of the conditioning two steps
+                // ahead; the gh1 gather (published a window ago; it queues behind the prefetch, which keeps the LDS pipe
+                // free for the critical waves' fc3 reads meanwhile); gh2 last, while the critical waves sit in the race
+                // exchange (measured: 3.40 vs 3.45 us/step against "gh2 first") ----
                 s_frame_consts();
                 s_prefetch(t + 2);
+                u64 gq[6];
+                peek_n<6>(mail, G_GH + par * 1536 + sidx, 256, gq);
+                finish_n<6, 32>(mail, G_GH + par * 1536 + sidx, 256, epoch, gq, dead, a.err, 15u);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) gh1s[sidx + m * 256] = __uint_as_float((unsigned)gq[m]);
+                P2(13);
                 {
                     // gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter (C read the
                     // old value back in phase B, three barriers ago)
@@ -594,12 +611,6 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                     sr = row_sum(sr) + cstQ[3]; sz = row_sum(sz) + cstQ[4]; sn = row_sum(sn) + cstQ[5];
                     if (q == 0) { hand[0] = sr; hand[1] = sz; hand[2] = sn; }
                 }
-                P2(13);
-                u64 gq[6];
-                peek_n<6>(mail, G_GH + par * 1536 + sidx, 256, gq);
-                finish_n<6, 32>(mail, G_GH + par * 1536 + sidx, 256, epoch, gq, dead, a.err, 15u);
-#pragma unroll
-                for (int m = 0; m < 6; ++m) gh1s[sidx + m * 256] = __uint_as_float((unsigned)gq[m]);
             }
             P2(11);
             __syncthreads();  // B5
@@ -628,9 +639,18 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             }
         }
         __syncthreads();
+        if (seg_end < a.steps) {   // hand the recurrent state to the next segment's launch
+            if (g == 0) {
+                st[tid] = h1_j;
+                st[512 + tid] = xb[XB_H2 * 512 + pj];
+                for (int i = tid; i < 1536; i += T2_THREADS) st[1024 + i] = gh1s[i];
+                if (tid == 0) st[4096] = xfeed;
+            }
+            if (!isC && q == 0) { st[2560 + unit] = hand[0]; st[2560 + 512 + unit] = hand[1]; st[2560 + 1024 + unit] = hand[2]; }
+        }
     }
-    if (PROF && a.prof && lane == 0 && g == 0) {
-        for (int i = 0; i < 17; ++i) a.prof[wave * 17 + i] = prof_acc[i];
+    if (PROF && a.prof && lane == 0 && g == 0 && team == 0) {
+        for (int i = 0; i < 17; ++i) a.prof[wave * 17 + i] += prof_acc[i];
     }
 }
 

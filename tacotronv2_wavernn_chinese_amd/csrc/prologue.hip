@@ -266,12 +266,13 @@ hipError_t wrnn_launch_pack_records(const float *CM, const float *CA, const floa
 // per step by the 32 workgroups of a team (1 HBM read + 31 L2 hits).  grid (ceil(steps/64), rows), block 512 (= unit).
 __global__ void __launch_bounds__(512)
 cond_stream_kernel(const float *__restrict__ rec, const float *__restrict__ ktab, const WrnnRow *__restrict__ rows,
-                   float4 *__restrict__ cond, int T, int HOP, long total_len, long steps) {
+                   float4 *__restrict__ cond, int T, int HOP, long total_len, long seg0, long seg_len) {
     const int j = threadIdx.x, row = blockIdx.y;
     const WrnnRow rw = rows[row];
     const float *recb = rec + (size_t)rw.utt * (T + 1) * 512 * 28;
-    const long t0 = (long)blockIdx.x * 64;
-    const long t1 = t0 + 64 < steps ? t0 + 64 : steps;
+    // steps seg0 .. seg0+seg_len-1 of every row -> cond[row][t - seg0]
+    const long t0 = seg0 + (long)blockIdx.x * 64;
+    const long t1 = t0 + 64 < seg0 + seg_len ? t0 + 64 : seg0 + seg_len;
     int cur = -1;
     float4 a0, a1, a2, a3, a4, a5;
     a0 = a1 = a2 = a3 = a4 = a5 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -292,14 +293,14 @@ cond_stream_kernel(const float *__restrict__ rec, const float *__restrict__ ktab
         c.y = fmaf(k4, a5.y, fmaf(k3, a4.z, fmaf(k2, a3.w, fmaf(k1, a3.x, fmaf(k0, a2.y, a0.y)))));
         c.z = fmaf(k4, a5.z, fmaf(k3, a4.w, fmaf(k2, a4.x, fmaf(k1, a3.y, fmaf(k0, a2.z, a0.z)))));
         c.w = fmaf(k4, a5.w, fmaf(k3, a5.x, fmaf(k2, a4.y, fmaf(k1, a3.z, fmaf(k0, a2.w, a0.w)))));
-        cond[((size_t)row * steps + t) * 512 + j] = c;
+        cond[((size_t)row * seg_len + (t - seg0)) * 512 + j] = c;
     }
 }
 
 hipError_t wrnn_launch_cond_stream(const float *rec, const float *ktab, const WrnnRow *rows, float *cond, int n_rows, int T,
-                                   int HOP, long total_len, long steps, hipStream_t s) {
+                                   int HOP, long total_len, long seg0, long seg_len, hipStream_t s) {
     (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
-    dim3 grid((unsigned)((steps + 63) / 64), n_rows);
-    hipLaunchKernelGGL(cond_stream_kernel, grid, dim3(512), 0, s, rec, ktab, rows, (float4 *)cond, T, HOP, total_len, steps);
+    dim3 grid((unsigned)((seg_len + 63) / 64), n_rows);
+    hipLaunchKernelGGL(cond_stream_kernel, grid, dim3(512), 0, s, rec, ktab, rows, (float4 *)cond, T, HOP, total_len, seg0, seg_len);
     return hipGetLastError();
 }

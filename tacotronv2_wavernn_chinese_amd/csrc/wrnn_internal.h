@@ -80,8 +80,10 @@ struct wrnn_handle {
     float *team_w = nullptr, *team_fc3 = nullptr, *wI0 = nullptr, *u1 = nullptr;
     float *tab = nullptr;         // CM|CA|VM|VA|C2|C3|C4 for the current batch
     size_t tab_cap = 0;
-    float *cond = nullptr;        // per-step conditioning stream (TEAM2)
+    float *cond = nullptr;        // conditioning stream of the current segment (TEAM2)
     size_t cond_cap = 0;
+    float *team_state = nullptr;  // recurrent state of every row between segment launches (TEAM2)
+    size_t team_state_cap = 0;
     unsigned long long *mail = nullptr;
     unsigned *ctl = nullptr;
     int n_teams = 8;              // XCDs (32-CU teams) of this device
@@ -119,6 +121,7 @@ struct WrnnLoopArgs {
 // x3, fc1, fc2, race winners (2 x 512 each), gh1 (2 x 1536)
 #define WRNN_TEAM_MAIL_GRANULES (8 * 512 + 2 * 1536)
 #define WRNN_TEAM_NWREG 352
+#define WRNN_TEAM_STATE_FLOATS (8 * 512 + 64)
 #define WRNN_TEAM_THREADS 256
 
 struct WrnnTeamArgs {
@@ -134,7 +137,7 @@ struct WrnnTeamArgs {
     //   VM (T+2P,3H) = W_ih1 . CM[f]                VA (T+1,3H) = W_ih1 . CA[i] + b_ih1
     // packed per frame and hidden unit, see pack_records_kernel (prologue.hip)
     const float *tabREC;      // (B, T+1, H, 28)
-    const float *tabCOND;     // (rows, steps, H, 4) per-step phase-A conditioning stream (TEAM2) or null
+    const float *tabCOND;     // (rows, seg_len, H, 4) phase-A conditioning stream of steps [seg0, seg0+seg_len) (TEAM2) or null
     const float *tabC2;       // (B, T+1, 3H)   W_ih2[:,H:] . a2[i] + b_ih2
     const float *tabC3;       // (B, T+1, FC)   fc1.W[:,H:] . a3[i] + b1
     const float *tabC4;       // (B, T+1, FC)   fc2.W[:,FC:] . a4[i] + b2
@@ -144,6 +147,11 @@ struct WrnnTeamArgs {
     int32_t T;
     int64_t total_len;
     int64_t steps;
+    // TEAM2 runs a row in segments (one launch each) so that the conditioning stream of a segment is still cache
+    // resident when it is read; the recurrent state crosses launches through `state`:
+    // per row [h1 H | h2 H | gh1 3H | gh2 3H | x 1 | pad] floats (WRNN_TEAM_STATE_FLOATS)
+    int64_t seg0, seg_len;
+    float *state;
     int32_t noise_mode;
     uint64_t seed;
     const float *noise1;
@@ -167,7 +175,7 @@ hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
 hipError_t wrnn_launch_loop_team(const WrnnTeamArgs &a, hipStream_t s);
 hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s);
 hipError_t wrnn_launch_cond_stream(const float *rec, const float *ktab, const WrnnRow *rows, float *cond, int n_rows, int T,
-                                   int HOP, long total_len, long steps, hipStream_t s);
+                                   int HOP, long total_len, long seg0, long seg_len, hipStream_t s);
 hipError_t wrnn_launch_pack_records(const float *CM, const float *CA, const float *VM, const float *VA, float *rec, int B,
                                     int T, int P, hipStream_t s);
 // out[b][f][n] = bias[n] + sum_k in(b,f,k) * Wt[k*ldw + n]; mode 0: row-major src (rows >= valid read as 0),

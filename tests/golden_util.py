@@ -11,7 +11,7 @@ from oracle.noise import noise_checksum, noise_from_seed
 from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz'))
+ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f[:4] in ('raw_', 'mol_'))   # dm_*: tests/test_deepmind.py
 RAW_CASES = [c for c in ALL_CASES if c.startswith('raw_')]
 MOL_CASES = [c for c in ALL_CASES if c.startswith('mol_')]
 

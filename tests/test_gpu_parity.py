@@ -147,6 +147,28 @@ def test_mol_parity(name, kernel):
     check_mol(res['samples'].cpu().numpy().T, res['labels'].cpu().numpy().T, reft, teacher_forced=True)
 
 
+@pytest.mark.parametrize('name', ['raw_peaky_b3_t21', 'raw_peaky_fold_t30', 'mol_default_b2_t21'])
+def test_segmented_launches_carry_the_recurrent_state(name, monkeypatch):
+    """The shipped kernel runs a row as a sequence of launches (one conditioning-stream chunk each) and hands
+    h1/h2/gh1/gh2/x over through device memory: with a tiny segment (dozens of launches per row, several rows
+    per team) the result must be what a single launch gives, and what the oracle gives."""
+    fx = load_case(name)
+    m = _model(fx, 'team2')
+    args = (fx['mels'], bool(fx.get('batched', False)), int(fx.get('target', 11000)), int(fx.get('overlap', 550)))
+    whole = m.generate_raw(*args, **_noise_kwargs(fx))
+    monkeypatch.setenv('WRNN_TEAM2_SEGMENT', '96')
+    parts = m.generate_raw(*args, **_noise_kwargs(fx))
+    monkeypatch.delenv('WRNN_TEAM2_SEGMENT')
+    assert whole['labels'].shape[1] > 10 * 96
+    np.testing.assert_array_equal(parts['labels'].cpu().numpy(), whole['labels'].cpu().numpy())
+    np.testing.assert_array_equal(parts['samples'].cpu().numpy(), whole['samples'].cpu().numpy())
+    ref = _oracle(fx)
+    if fx['mode'] == 'RAW':
+        check_free_run_raw(parts['labels'].cpu().numpy().T, ref)
+    else:
+        check_mol(parts['samples'].cpu().numpy().T, parts['labels'].cpu().numpy().T, ref, teacher_forced=False)
+
+
 @pytest.mark.parametrize('name', ['raw_peaky_b1_t24', 'raw_peaky_fold_t30', 'raw_peaky_b3_t21', 'mol_default_b1_t24'])
 def test_generate_end_to_end_wav(name, tmp_path):
     """The full drop-in call: generate() return value vs the reference's own wav (float64)."""
