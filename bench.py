@@ -14,7 +14,7 @@ collective -- utterances are independent).
 Extra objects on the JSON line:
   roofline     -- memory-bound roofline of the batch-1 loop kernel: ALGORITHMIC bytes
                   (17 371 136 B of fp32 loop parameters + 836 B conditioning/sample per
-                  step) x steps per launch / the loop kernel's duration
+                  step) x steps per launch / the loop kernel's average launch duration
                   (HIP events recorded by the library on the launch stream) vs 8 TB/s.
   cpu_baseline -- the CPU restatement (oracle/, "port") timed on this box's host cores on
                   a bounded sample of the same workload (rank 0, N=1 only).
@@ -39,10 +39,10 @@ SAMPLE_RATE = 22050
 BYTES_PER_SAMPLE_B1 = 17_371_136 + 836   # W + (C + O) at B = 1
 FLOP_PER_SAMPLE = 8_668_160
 HBM_PEAK = 8.0e12                   # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of one loop-kernel launch on the T=401 workload from the PMC passes in profiles/r01_rocprofv3_bench_team*.txt
-# (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE): weights once + per-frame records
-TRAFFIC_BYTES_PER_LAUNCH = {2: int((20082.2 * 2 + 1309.6) * 1024),    # team : weights once + per-frame records
-                            3: 923_299_008}                           # team2: weights once + the 8 KB/step conditioning stream
+# HBM bytes of the loop kernel over ONE utterance of the T=401 workload from the PMC passes in
+# profiles/r01_rocprofv3_bench_team*.txt (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE)
+TRAFFIC_BYTES_PER_UTTERANCE = {2: int((20082.2 * 2 + 1309.6) * 1024),           # team : weights once + per-frame records (1 launch)
+                               3: int((542750.375 * 2 + 24372.96875) * 1024)}   # team2: 14 launches: weights 14x + the 8 KB/step stream + state
 
 
 def cpu_baseline(frames: int = 61, max_threads: int = 16) -> dict:
@@ -144,7 +144,9 @@ def main() -> int:
         value = total_samples / dt / 1000.0
         audio_s = (T - 1) * HOP / SAMPLE_RATE
         k_ms = float(np.mean(loop_ms))
-        achieved = BYTES_PER_SAMPLE_B1 * rows * L / (k_ms * 1e-3)
+        launches = max(1, int(tm.get('launches', 1)))    # segments one utterance is generated in
+        achieved = (BYTES_PER_SAMPLE_B1 * rows * L / launches) / (k_ms * 1e-3 / launches)
+        traffic = TRAFFIC_BYTES_PER_UTTERANCE.get(kernel_ran) if T == T_FRAMES else None
         out = {
             'metric': 'audio ksamples/sec (22.05 kHz, 10-bit RAW WaveRNN, batch=1 per GPU)',
             'value': round(value, 3), 'unit': 'ksamples/s', 'n_gpus': world, 'steps': args.steps,
@@ -157,12 +159,15 @@ def main() -> int:
                        'real_time_factor': round((dt / args.steps) / audio_s, 4),
                        'times_real_time': round(audio_s / (dt / args.steps), 2),
                        'prologue_ms': round(float(np.mean(pro_ms)), 3), 'loop_kernel_ms': round(k_ms, 3),
+                       'loop_launches_per_utterance': launches, 'loop_launch_avg_ms': round(k_ms / launches, 3),
                        'parallelism': f'utterance-parallel x{world} (no data-path collective)'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved / 1e9, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK, 4), 'traffic': TRAFFIC_BYTES_PER_LAUNCH.get(kernel_ran) if T == T_FRAMES else None,
-                         'note': 'achieved = algorithmic bytes (17 371 972 B/sample at B=1) x steps per launch / loop-kernel duration; '
-                                 'traffic = measured HBM bytes per launch (PMC passes, profiles/): the weights are register/LDS '
-                                 'resident, so the kernel is latency/issue-bound, not HBM-bound'},
+                         'frac': round(achieved / HBM_PEAK, 4), 'traffic': None if traffic is None else traffic // launches,
+                         'note': 'achieved = algorithmic bytes (17 371 972 B/sample at B=1) x steps per launch / average loop-kernel '
+                                 'launch duration (an utterance is generated in loop_launches_per_utterance launches; HIP events '
+                                 'around the whole sequence / launches); traffic = measured HBM bytes per launch (PMC passes, '
+                                 'profiles/): the weights are register/LDS resident, so the kernel is latency/issue-bound, not '
+                                 'HBM-bound'},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

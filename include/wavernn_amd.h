@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 1
+#define WRNN_ABI_VERSION 2
 
 /* mode: fatchord_version.py:98-103 */
 #define WRNN_MODE_RAW 0 /* softmax over 2**bits classes */
@@ -111,6 +111,8 @@ typedef struct wrnn_timing {
     int32_t kernel;    /* WRNN_KERNEL_* that actually ran */
     int32_t rows;      /* rows the loop processed (B or num_folds) */
     int64_t steps;     /* loop length per row */
+    int32_t launches;  /* loop-kernel launches the call was split into (segments) */
+    int32_t reserved_;
 } wrnn_timing;
 
 /* replaces WaveRNN.__init__ (fatchord_version.py:93-129) */

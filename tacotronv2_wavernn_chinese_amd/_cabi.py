@@ -57,7 +57,7 @@ class SampleOpts(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [('prologue_ms', C.c_float), ('loop_ms', C.c_float), ('kernel', C.c_int32), ('rows', C.c_int32),
-                ('steps', C.c_int64)]
+                ('steps', C.c_int64), ('launches', C.c_int32), ('reserved_', C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -227,7 +227,8 @@ class NativeVocoder:
     def last_timing(self) -> dict:
         t = Timing()
         self._check(self.lib.wrnn_last_timing(self._h, C.byref(t)))
-        return dict(prologue_ms=t.prologue_ms, loop_ms=t.loop_ms, kernel=t.kernel, rows=t.rows, steps=t.steps)
+        return dict(prologue_ms=t.prologue_ms, loop_ms=t.loop_ms, kernel=t.kernel, rows=t.rows, steps=t.steps,
+                    launches=t.launches)
 
 
 def _tensor_descs(state_dict: Dict[str, np.ndarray]):

@@ -423,6 +423,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     a.x_forced = opts->x_forced_dev; a.logits_out = opts->logits_out_dev; a.labels_out = labels_out_dev;
     a.samples_out = samples_out_dev; a.err = h->err_dev;
     int kernel = opts->kernel;
+    int launches = 1;
     if (kernel == WRNN_KERNEL_AUTO) {
         kernel = WRNN_KERNEL_TEAM2;
     }
@@ -500,6 +501,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
                 HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
                 ta.seg0 = t0; ta.seg_len = len;
                 HIP_TRY(h, wrnn_launch_loop_team2(ta, s));
+                launches = (int)(t0 / seg) + 1;
             }
         } else {
             HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
@@ -512,7 +514,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     }
     HIP_TRY(h, hipEventRecord(h->ev[2], s));
     h->timing_valid = true;
-    h->last.kernel = kernel; h->last.rows = rows; h->last.steps = steps;
+    h->last.kernel = kernel; h->last.rows = rows; h->last.steps = steps; h->last.launches = launches;
     return WRNN_OK;
 }
 

@@ -98,11 +98,23 @@ __device__ __forceinline__ float row_sum(float v) {   // sum over the 16 lanes o
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {   // max over 64 lanes, valid in lane 63
-#define WMAX_STEP(CTRL, RM) \
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false)))
-    WMAX_STEP(0xB1, 0xf); WMAX_STEP(0x4E, 0xf); WMAX_STEP(0x141, 0xf); WMAX_STEP(0x140, 0xf);
-    WMAX_STEP(0x142, 0xa); WMAX_STEP(0x143, 0xc);
-#undef WMAX_STEP
+    // One v_max_f32_dpp per step (the compiler's fmaxf + update_dpp form costs 4 VALU per step: copy, DPP move, two
+    // canonicalising maxes).  s_nop 1 = the two wait states a DPP read of a just-written VGPR needs.
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 
