@@ -357,6 +357,17 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         };
         // S: sampling noise of step ts for the paired C quarter -> hand[4 + 2*parity(ts) ...]
         auto s_noise = [&](int64_t ts, unsigned ep_of_ts) {
+            if (MODE == WRNN_MODE_MOL && wave == 4 && lane <= NC / 3) {
+                // MOL (distribution.py:106-121): the Gumbel noise of the mixture pick (lanes 0..9) and the logistic
+                // noise of the sample (lane 10) do not depend on the logits: drawn one step ahead, off the critical path
+                const int nr = NC / 3;
+                float u;
+                if (a.noise_mode == WRNN_NOISE_INJECTED)
+                    u = lane < nr ? a.noise1[((size_t)ts * a.n_rows + row) * nr + lane] : a.noise2[(size_t)ts * a.n_rows + row];
+                else
+                    u = 1e-5f + wrnn_uniform(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)lane) * (1.0f - 2e-5f);
+                misc_f[32 + 16 * (ep_of_ts & 1u) + lane] = lane < nr ? -logf(-logf(u)) : logf(u) - logf(1.0f - u);
+            }
             if (MODE == WRNN_MODE_RAW && has_fc3) {
                 float nz0 = 0.f, nz1 = 0.f;
                 if (a.noise_mode == WRNN_NOISE_INJECTED) {
@@ -576,22 +587,13 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                             }
                             mylg = __uint_as_float((unsigned)gq[0]);
                         }
-                        float v = -INFINITY;
-                        if (lane < nr) {
-                            float u1;
-                            if (a.noise_mode == WRNN_NOISE_INJECTED) u1 = a.noise1[((size_t)t * a.n_rows + row) * nr + lane];
-                            else u1 = 1e-5f + wrnn_uniform(a.seed, (uint64_t)t, (uint32_t)row, (uint32_t)lane) * (1.0f - 2e-5f);
-                            v = mylg - logf(-logf(u1));
-                        }
+                        const float v = lane < nr ? mylg + misc_f[32 + 16 * par + lane] : -INFINITY;
                         const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max(v)), 63));
                         const u64 ball = __ballot(v == mx);
                         const int km = (int)__builtin_ctzll(ball ? ball : 1ull);
                         const float mean = __shfl(mylg, nr + km, 64);
                         const float ls = fmaxf(__shfl(mylg, 2 * nr + km, 64), -32.23619130191664f);
-                        float u2;
-                        if (a.noise_mode == WRNN_NOISE_INJECTED) u2 = a.noise2[(size_t)t * a.n_rows + row];
-                        else u2 = 1e-5f + wrnn_uniform(a.seed, (uint64_t)t, (uint32_t)row, 10u) * (1.0f - 2e-5f);
-                        float xs = mean + expf(ls) * (logf(u2) - logf(1.0f - u2));
+                        float xs = mean + expf(ls) * misc_f[32 + 16 * par + nr];
                         xs = fminf(fmaxf(xs, -1.0f), 1.0f);
                         if (lane == 0) {
                             misc_f[M_XF] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + row] : xs;
