@@ -147,6 +147,15 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
                   int32_t target, int32_t overlap, const wrnn_sample_opts *opts, int32_t *labels_out_dev,
                   float *samples_out_dev, void *stream);
 
+/* replaces the float64 tail of generate() (fatchord_version.py:243-258): decode_mu_law (wavernn/utils/dsp.py:98-103)
+ * when mu_law != 0 on a RAW model (needs labels_dev), xfade_and_unfold (:342-405) when batched != 0, the trim to
+ * wave_len and the 20-hop linear fade-out (:255-258).  samples_dev / labels_dev: (rows, steps) as written by
+ * wrnn_generate; wave_out_dev: wave_len doubles.  Unbatched calls use row 0 only, like :253.  wave_len shorter than
+ * 20 hops is WRNN_ERR_INVALID (the reference raises ValueError for T < 21).  Asynchronous on `stream`. */
+int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int32_t *labels_dev, int32_t rows, int64_t steps,
+                  int32_t batched, int32_t target, int32_t overlap, int32_t mu_law, int64_t wave_len,
+                  double *wave_out_dev, void *stream);
+
 /* Blocks until the last wrnn_generate on this handle finished, then reports
  * HIP-event timings and any device-side error (WRNN_ERR_TIMEOUT). */
 int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out);

@@ -26,7 +26,7 @@ ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN
 # every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
-                    'wrnn_abi_version', 'wrnn_destroy',
+                    'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy')
 
 
@@ -107,6 +107,9 @@ def load_library() -> C.CDLL:
     lib.wrnn_generate.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(SampleOpts), vp, vp, vp]
     lib.wrnn_generate.restype = C.c_int
+    lib.wrnn_epilogue.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                  vp, vp]
+    lib.wrnn_epilogue.restype = C.c_int
     lib.wrnn_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.wrnn_last_timing.restype = C.c_int
     lib.wrnn_n_classes.argtypes = [vp]
@@ -223,6 +226,12 @@ class NativeVocoder:
         o.x_forced_dev, o.logits_out_dev = x_forced_ptr or None, logits_ptr or None
         self._check(self.lib.wrnn_generate(self._h, mels_ptr, B, T, int(bool(batched)), int(target), int(overlap),
                                            C.byref(o), labels_ptr or None, samples_ptr, stream or None))
+
+    def epilogue(self, samples_ptr: int, labels_ptr: int, rows: int, steps: int, batched: bool, target: int,
+                 overlap: int, mu_law: bool, wave_len: int, out_ptr: int, stream: int):
+        self._check(self.lib.wrnn_epilogue(self._h, samples_ptr, labels_ptr or None, rows, steps, int(bool(batched)),
+                                           int(target), int(overlap), int(bool(mu_law)), int(wave_len), out_ptr,
+                                           stream or None))
 
     def last_timing(self) -> dict:
         t = Timing()

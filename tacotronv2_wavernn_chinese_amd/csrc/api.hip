@@ -131,6 +131,7 @@ void wrnn_destroy(wrnn_handle *h) {
     if (h->tab) (void)hipFree(h->tab);
     if (h->cond) (void)hipFree(h->cond);
     if (h->team_state) (void)hipFree(h->team_state);
+    if (h->epi_tab) (void)hipFree(h->epi_tab);
     if (h->mail) (void)hipFree(h->mail);
     if (h->ctl) (void)hipFree(h->ctl);
     for (int i = 0; i < 3; ++i)

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, 1) loop_team_kernel(WrnnTeamArgs
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r4 = lane >> 4, q = lane & 15;
     const WrnnDims d = a.d;
-    const int NC = d.NC, HOP = d.HOP, ND = d.ND, T = a.T;
+    const int NC = d.NC, HOP = d.HOP, T = a.T;
 
     // ---- team formation: by the XCD this workgroup actually runs on ------------
     if (tid == 0) {

@@ -201,7 +201,7 @@ constexpr int L_SW = L_XB + 6 * 512;           // [8 planes][256 S-threads][4]: 
 constexpr int L_FC3 = L_SW + 8 * 256 * 4;      // [4 C-waves][2 rows][8 planes][64 lanes][4]
 constexpr int L_TOTAL = L_FC3 + 16384;
 static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
-constexpr int M_XF = 9, M_K = 8, M_DEAD = 10;  // misc slots: fed-back sample, label, bail-out flag
+constexpr int M_XF = 9, M_DEAD = 10;  // misc slots: fed-back sample, bail-out flag
 
 constexpr unsigned G_X3 = 0, G_F1 = 1024, G_F2 = 2048, G_PR = 3072, G_GH = 4096;  // mailbox regions (granules)
 

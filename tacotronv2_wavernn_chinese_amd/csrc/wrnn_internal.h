@@ -82,6 +82,8 @@ struct wrnn_handle {
     size_t tab_cap = 0;
     float *cond = nullptr;        // conditioning stream of the current segment (TEAM2)
     size_t cond_cap = 0;
+    double *epi_tab = nullptr;    // epilogue tables [dec NC | fade_in | fade_out | tail] for epi_overlap
+    long epi_overlap = -1;
     float *team_state = nullptr;  // recurrent state of every row between segment launches (TEAM2)
     size_t team_state_cap = 0;
     unsigned long long *mail = nullptr;

@@ -183,7 +183,18 @@ class WaveRNN(nn.Module):
             del keep
         return dict(samples=samples, labels=labels, logits=logits, rows=rows, steps=steps)
 
-    def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law, **native_opts):
+    def epilogue_device(self, res, batched, target, overlap, mu_law, wave_len):
+        """float64 tail of generate() (:243-258) on the GPU (``wrnn_epilogue``): (wave_len,) float64 cuda tensor."""
+        nat = self.native()
+        dev = res['samples'].device
+        with torch.cuda.device(dev):
+            out = torch.empty((int(wave_len),), dtype=torch.float64, device=dev)
+            nat.epilogue(res['samples'].data_ptr(), res['labels'].data_ptr(), res['rows'], res['steps'], batched, target,
+                         overlap, mu_law, wave_len, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        return out
+
+    def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law, epilogue='host',
+                 **native_opts):
         """Same contract as the reference ``generate`` (:169-264), including its quirks:
         generates T*hop samples but returns (T-1)*hop (:184,:257); raises ``ValueError`` for T < 21
         (fade-out broadcast, :256-258); an unbatched call with B > 1 returns only utterance 0 (:253);
@@ -191,6 +202,8 @@ class WaveRNN(nn.Module):
         (:245); the model is left in train mode (:262) and a wav is always written (:260).
         Sampling draws from a device counter RNG seeded from the global torch generator, so
         ``torch.manual_seed`` makes a call reproducible like it does for the reference.
+        ``epilogue='device'`` runs decode / unfold / fade-out on the GPU (tables built like NumPy builds them;
+        identical output up to the host libm's ``pow``) instead of the float64 NumPy pass on the host.
         """
         self.eval()
         mu_law = mu_law if self.mode == 'RAW' else False
@@ -200,9 +213,19 @@ class WaveRNN(nn.Module):
         if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) == _cabi.NOISE_PHILOX:
             native_opts['seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
         res = self.generate_raw(mels_t, batched, target, overlap, **native_opts)
-        output = res['samples'].cpu().numpy().astype(np.float64)  # (rows, L)   :243-245
         if self.verbose:
             self.gen_display(res['steps'] - 1, res['steps'], res['rows'], start)
+        if epilogue == 'device':
+            if wave_len < 20 * self.hop_length:   # the broadcast error of :258
+                raise ValueError(f'operands could not be broadcast together with shapes ({max(wave_len, 0)},) '
+                                 f'({20 * self.hop_length},) ({max(wave_len, 0)},)')
+            output = self.epilogue_device(res, batched, target, overlap, mu_law, wave_len).cpu().numpy()
+            save_wav(output, save_path, self.sample_rate)
+            self.train()
+            return output
+        if epilogue != 'host':
+            raise ValueError(f"epilogue must be 'host' or 'device', got {epilogue!r}")
+        output = res['samples'].cpu().numpy().astype(np.float64)  # (rows, L)   :243-245
 
         if mu_law:
             output = decode_mu_law(output, self.n_classes, False)

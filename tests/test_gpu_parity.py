@@ -170,6 +170,39 @@ def test_segmented_launches_carry_the_recurrent_state(name, monkeypatch):
 
 
 @pytest.mark.parametrize('name', ['raw_peaky_b1_t24', 'raw_peaky_fold_t30', 'raw_peaky_b3_t21', 'mol_default_b1_t24'])
+@pytest.mark.parametrize('mu_law', [True, False])
+def test_device_epilogue_matches_numpy_float64(name, mu_law):
+    """wrnn_epilogue (decode_mu_law + xfade_and_unfold + trim + fade-out on the GPU, float64) against the
+    oracle's NumPy restatement of fatchord_version.py:243-258 on the same samples.  Everything but pow() is
+    the same IEEE operation sequence; tolerance: 4 ulp of the largest magnitude."""
+    fx = load_case(name)
+    m = _model(fx, 'team2')
+    batched, target, overlap = bool(fx.get('batched', False)), int(fx.get('target', 11000)), int(fx.get('overlap', 550))
+    res = m.generate_raw(fx['mels'], batched, target, overlap, **_noise_kwargs(fx))
+    T = fx['mels'].shape[-1]
+    wave_len = (T - 1) * 275
+    mu = mu_law and fx['mode'] == 'RAW'
+    want = orc.epilogue(res['samples'].cpu().numpy(), m.n_classes, mu, batched, target, overlap, wave_len, 275)
+    got = m.epilogue_device(res, batched, target, overlap, mu, wave_len).cpu().numpy()
+    assert got.dtype == np.float64 and got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=4 * np.finfo(np.float64).eps)
+    assert np.count_nonzero(got != want) <= got.size // 100     # pow() rounding only, if at all
+
+
+def test_device_epilogue_rejects_what_the_reference_rejects():
+    from tacotronv2_wavernn_chinese_amd._cabi import WrnnError
+    fx = load_case('raw_peaky_b1_t24')
+    m = _model(fx, 'team2')
+    res = m.generate_raw(fx['mels'], False, 11000, 550, **_noise_kwargs(fx))
+    with pytest.raises(WrnnError):      # T < 21: shorter than the 20-hop fade-out (:258 raises ValueError)
+        m.epilogue_device(res, False, 11000, 550, True, 19 * 275)
+    with pytest.raises(WrnnError):      # longer than what was generated
+        m.epilogue_device(res, False, 11000, 550, True, res['steps'] + 1)
+    with pytest.raises(WrnnError):      # folds of the wrong length
+        m.epilogue_device(res, True, 11000, 550, True, 23 * 275)
+
+
+@pytest.mark.parametrize('name', ['raw_peaky_b1_t24', 'raw_peaky_fold_t30', 'raw_peaky_b3_t21', 'mol_default_b1_t24'])
 def test_generate_end_to_end_wav(name, tmp_path):
     """The full drop-in call: generate() return value vs the reference's own wav (float64)."""
     from tacotronv2_wavernn_chinese_amd import _cabi
@@ -187,6 +220,10 @@ def test_generate_end_to_end_wav(name, tmp_path):
         same = all(f is None for f in check_free_run_raw(res['labels'].cpu().numpy().T, ref))
         if same:
             np.testing.assert_array_equal(wav, fx['wav'])
+            # the same call with the float64 tail on the GPU, against the reference's own wav
+            wav_dev = m.generate(fx['mels'], out, bool(fx['batched']), int(fx['target']), int(fx['overlap']), True,
+                                 epilogue='device', **_noise_kwargs(fx))
+            np.testing.assert_allclose(wav_dev, fx['wav'], rtol=0, atol=4 * np.finfo(np.float64).eps)
     else:
         if (res['labels'].cpu().numpy().T == ref['labels']).all():
             np.testing.assert_allclose(wav, fx['wav'], rtol=0, atol=1e-4)
