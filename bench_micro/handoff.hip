@@ -297,6 +297,70 @@ static void run_gather2(GatherCtl *ctl, u64 *mail, int rounds) {
            wmax * 0.01 / rounds, cmax / rounds);
 }
 
+// gather3: NO LDS staging and no workgroup barrier -- each of PW waves of a workgroup polls the whole 512-granule
+// vector itself (8 granules per lane: granules 4l..4l+3 and 256+4l..256+4l+3, four dwordx4 loads per look), wave 0
+// publishes the workgroup's 16 values of the next round once its own poll completed.  Measures whether the XCD's L2
+// sustains 32 WGs x PW waves re-reading the same 4 KB (the "column-sliced direct poll" exchange).
+template <int PW>
+__global__ void __launch_bounds__(512) gather3_kernel(GatherCtl *ctl, u64 *mail, int xcd_sel, int rounds) {
+    __shared__ int rank_s;
+    if (threadIdx.x == 0) {
+        unsigned x = xcc_id();
+        unsigned r_local = atomicAdd(&ctl->arrivals[x], 1u);
+        atomicAdd(&ctl->total, 1u);
+        rank_s = ((int)x == xcd_sel && (int)r_local < 32) ? (int)r_local : -1;
+    }
+    __syncthreads();
+    const int rank = rank_s;
+    if (rank < 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (wave >= PW) return;
+    const unsigned SPIN_MAX = 2000000;
+    float acc = 0.f, myval = (float)rank;
+    u64 c0 = 0, w0 = 0;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    for (int r = 1; r <= rounds + 16; ++r) {
+        if (r == 17 && tid == 0) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
+        u64 *buf = mail + (size_t)(r & 1) * 512;
+        if (wave == 0 && lane < 16) st64<ST_PLAIN>(buf + rank * 16 + lane, ((u64)r << 32) | __float_as_uint(myval + lane));
+        const u4 *p0 = (const u4 *)(buf + 4 * lane), *p1 = (const u4 *)(buf + 256 + 4 * lane);
+        unsigned spins = 0;
+        u4 a, b, c, d;
+        for (;;) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a) : "v"(p0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=&v"(b) : "v"(p0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(c) : "v"(p1) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=&v"(d) : "v"(p1) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+            const bool ok = a.y == (unsigned)r && a.w == (unsigned)r && b.y == (unsigned)r && b.w == (unsigned)r &&
+                            c.y == (unsigned)r && c.w == (unsigned)r && d.y == (unsigned)r && d.w == (unsigned)r;
+            if (__all(ok)) break;
+            if (++spins > SPIN_MAX) { atomicExch(&ctl->err, 6u); return; }
+        }
+        float s = __uint_as_float(a.x) + __uint_as_float(a.z) + __uint_as_float(b.x) + __uint_as_float(b.z) +
+                  __uint_as_float(c.x) + __uint_as_float(c.z) + __uint_as_float(d.x) + __uint_as_float(d.z);
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        acc += s;
+        myval = s * 1e-9f + (float)rank;
+    }
+    if (tid == 0) { ctl->cycles[rank] = __builtin_readcyclecounter() - c0; ctl->wall[rank] = wall_clock64() - w0; }
+    if (lane == 1) ctl->checksum[rank] = acc;
+}
+
+template <int PW>
+static void run_gather3(GatherCtl *ctl, u64 *mail, int rounds) {
+    CHECK(hipMemset(ctl, 0, sizeof(GatherCtl)));
+    CHECK(hipMemset(mail, 0, 2 * 1024 * sizeof(u64)));
+    gather3_kernel<PW><<<256, 512, 0>>>(ctl, mail, 0, rounds);
+    CHECK(hipDeviceSynchronize());
+    static GatherCtl h;
+    CHECK(hipMemcpy(&h, ctl, sizeof(h), hipMemcpyDeviceToHost));
+    double wmax = 0, cmax = 0;
+    for (int i = 0; i < 32; ++i) { if (h.wall[i] > wmax) wmax = (double)h.wall[i]; if (h.cycles[i] > cmax) cmax = (double)h.cycles[i]; }
+    printf("gather3 (direct poll, no LDS/barrier) waves/WG=%d err=%u  per-round %.3f us (%.0f cycles)\n", PW, h.err,
+           wmax * 0.01 / rounds, cmax / rounds);
+}
+
 // ----------------------------------------------------------------- driver
 static const size_t LDS_BIG = 96 * 1024;  // > 80 KiB: one workgroup per CU
 
@@ -409,6 +473,9 @@ int main(int argc, char **argv) {
     run_gather2<8, 0, 1>(gc, mail, rounds);
     run_gather2<1, 1, 0>(gc, mail, rounds);
     run_gather2<1, 1, 1>(gc, mail, rounds);
+    run_gather3<1>(gc, mail, rounds);
+    run_gather3<4>(gc, mail, rounds);
+    run_gather3<8>(gc, mail, rounds);
     printf("done\n");
     return 0;
 }
