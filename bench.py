@@ -108,12 +108,17 @@ def main() -> int:
     rows, L = nat.plan(1, T, False, 11000, 550)
     samples = torch.empty((rows, L), dtype=torch.float32, device=dev)
     labels = torch.empty((rows, L), dtype=torch.int32, device=dev)
+    wave_len = (T - 1) * HOP
+    wave = torch.empty((wave_len,), dtype=torch.float64, device=dev)   # what generate() returns (:264)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def one_step(i: int):
         nat.generate(mels.data_ptr(), 1, T, False, 11000, 550, labels_ptr=labels.data_ptr(),
                      samples_ptr=samples.data_ptr(), stream=stream, noise_mode=_cabi.NOISE_PHILOX,
                      seed=0xC0FFEE + 7919 * i + rank, kernel=model.kernel)
+        # float64 tail of generate() (mu-law decode, trim, fade-out) on the device: the step ends with the waveform
+        nat.epilogue(samples.data_ptr(), labels.data_ptr(), rows, L, False, 11000, 550, True, wave_len,
+                     wave.data_ptr(), stream)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -153,7 +158,7 @@ def main() -> int:
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: 1 utterance per GPU per step, B=1, mel 80x{T} '
-                                   f'({L} loop steps = {audio_s:.3f} s audio), RAW 10-bit, hop 275, prologue+loop, '
+                                   f'({L} loop steps = {audio_s:.3f} s audio), RAW 10-bit, hop 275, prologue + loop + float64 epilogue on the device, '
                                    'Philox sampling noise, seeded synthetic weights (fc3 x128)',
                        'kernel': {1: 'simple', 2: 'team', 3: 'team2'}.get(kernel_ran, str(kernel_ran)),
                        'real_time_factor': round((dt / args.steps) / audio_s, 4),

@@ -178,6 +178,11 @@ int wrnn_dm_create(int32_t hidden_size, int32_t quantisation, int32_t device, wr
 int wrnn_dm_load_weights(wrnn_dm_handle *h, const wrnn_tensor_desc *tensors, int32_t n);
 int wrnn_dm_generate(wrnn_dm_handle *h, int64_t seq_len, int32_t noise_mode, uint64_t seed, const float *noise_dev,
                      int32_t *coarse_out_dev, int32_t *fine_out_dev, void *stream);
+/* kernel: 0 auto (the 32-workgroup team kernel when hidden_size is 512/640/768/896 and quantisation a multiple of
+ * 64, else the single-workgroup kernel), 1 single workgroup (reference-ordered sums), 2 team */
+int wrnn_dm_set_kernel(wrnn_dm_handle *h, int32_t kernel);
+/* synchronises `stream` and reports the device-side error word of the team kernel (WRNN_ERR_TIMEOUT) */
+int wrnn_dm_sync_status(wrnn_dm_handle *h, void *stream);
 const char *wrnn_dm_last_error(const wrnn_dm_handle *h);
 void wrnn_dm_destroy(wrnn_dm_handle *h);
 

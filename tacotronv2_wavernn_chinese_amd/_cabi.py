@@ -27,7 +27,8 @@ ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
                     'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue',
-                    'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy')
+                    'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
+                    'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
 
 
 class WrnnError(RuntimeError):
@@ -128,6 +129,10 @@ def load_library() -> C.CDLL:
     lib.wrnn_dm_load_weights.restype = C.c_int
     lib.wrnn_dm_generate.argtypes = [vp, C.c_int64, C.c_int32, C.c_uint64, vp, vp, vp, vp]
     lib.wrnn_dm_generate.restype = C.c_int
+    lib.wrnn_dm_set_kernel.argtypes = [vp, C.c_int32]
+    lib.wrnn_dm_set_kernel.restype = C.c_int
+    lib.wrnn_dm_sync_status.argtypes = [vp, vp]
+    lib.wrnn_dm_sync_status.restype = C.c_int
     lib.wrnn_dm_last_error.argtypes = [vp]
     lib.wrnn_dm_last_error.restype = C.c_char_p
     lib.wrnn_dm_destroy.argtypes = [vp]
@@ -293,3 +298,7 @@ class NativeDeepmind:
                  seed: int = 0, noise_ptr: int = 0):
         self._check(self.lib.wrnn_dm_generate(self._h, int(seq_len), noise_mode, seed & 0xFFFFFFFFFFFFFFFF,
                                               noise_ptr or None, coarse_ptr, fine_ptr, stream or None))
+        self._check(self.lib.wrnn_dm_sync_status(self._h, stream or None))   # waits; surfaces device-side errors
+
+    def set_kernel(self, kernel: int):
+        self._check(self.lib.wrnn_dm_set_kernel(self._h, int(kernel)))

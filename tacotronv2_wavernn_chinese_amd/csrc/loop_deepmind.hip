@@ -7,16 +7,7 @@
 
 #define DM_THREADS 1024
 
-struct WrnnDmArgs {
-    const float *w;        // packed: RT [H][3H] | O1T [S][S] | O1b | O2T [S][Q] | O2b | O3T | O3b | O4T | O4b | Ic [3S][2] | If [3S][3] | bu | br | be
-    size_t oRT, oO1T, oO1b, oO2T, oO2b, oO3T, oO3b, oO4T, oO4b, oIc, oIf, obu, obr, obe;
-    int H, Q;
-    long seq_len;
-    int noise_mode;
-    unsigned long long seed;
-    const float *noise;    // (seq_len, 2, Q) Exp(1) draws or null
-    int *coarse, *fine;
-};
+#include "dm_internal.h"
 
 namespace {
 
@@ -128,6 +119,10 @@ struct wrnn_dm_handle {
     float *wdev = nullptr;
     WrnnDmArgs args{};
     bool loaded = false;
+    int kernel = 0;               // 0 auto (team kernel when the sizes allow), 1 single-workgroup kernel, 2 team kernel
+    float *team_w = nullptr, *team_lds = nullptr;
+    unsigned long long *mail = nullptr;
+    unsigned *ctl = nullptr;      // [32] team counters + [32] error word
     std::string err;
 };
 
@@ -162,7 +157,12 @@ int wrnn_dm_create(int32_t hidden_size, int32_t quantisation, int32_t device, wr
 
 void wrnn_dm_destroy(wrnn_dm_handle *h) {
     if (!h) return;
-    if (h->wdev) { (void)hipSetDevice(h->device); (void)hipFree(h->wdev); }
+    (void)hipSetDevice(h->device);
+    if (h->wdev) (void)hipFree(h->wdev);
+    if (h->team_w) (void)hipFree(h->team_w);
+    if (h->team_lds) (void)hipFree(h->team_lds);
+    if (h->mail) (void)hipFree(h->mail);
+    if (h->ctl) (void)hipFree(h->ctl);
     delete h;
 }
 
@@ -215,7 +215,62 @@ int wrnn_dm_load_weights(wrnn_dm_handle *h, const wrnn_tensor_desc *tensors, int
     if (h->wdev) { (void)hipFree(h->wdev); h->wdev = nullptr; }
     DM_TRY(h, hipMalloc(&h->wdev, cur * sizeof(float)));
     DM_TRY(h, hipMemcpy(h->wdev, pk.data(), cur * sizeof(float), hipMemcpyHostToDevice));
+    // ---- team kernel layouts (loop_dm_team.hip) ----
+    if (wrnn_dm_team_supported(H, Q)) {
+        const int U = S / 32, QW = Q / 32, CPL = H / 64, PS = CPL / 2, NR = 3 * CPL * 4;
+        const float *R, *O1, *O2, *O3, *O4;
+        if ((rc = get("R.weight", (int64_t)3 * H * H, &R)) || (rc = get("O1.weight", (int64_t)S * S, &O1)) ||
+            (rc = get("O2.weight", (int64_t)Q * S, &O2)) || (rc = get("O3.weight", (int64_t)S * S, &O3)) ||
+            (rc = get("O4.weight", (int64_t)Q * S, &O4)))
+            return rc;
+        std::vector<float> tw((size_t)32 * NR * 512, 0.0f);
+        const size_t nimg = (size_t)2 * U * S + (size_t)2 * QW * S;
+        std::vector<float> tl((size_t)32 * nimg, 0.0f);
+        for (int g = 0; g < 32; ++g) {
+            for (int tid = 0; tid < 512; ++tid) {
+                const int qw = tid >> 4, q = tid & 15;
+                if (qw >= 2 * U) continue;
+                const int hi = qw < U ? g * U + qw : S + g * U + (qw - U);
+                for (int gate = 0; gate < 3; ++gate)
+                    for (int c = 0; c < 4 * CPL; ++c)
+                        tw[((size_t)g * NR + gate * 4 * CPL + c) * 512 + tid] = R[(size_t)(gate * H + hi) * H + q * 4 * CPL + c];
+            }
+            // LDS images: [row of the workgroup][plane k][lane q][4] <- W[row][q * 4 PS + 4 k + e]
+            float *img = tl.data() + (size_t)g * nimg;
+            auto fill = [&](float *dst, const float *W, int row0, int nrows) {
+                for (int r = 0; r < nrows; ++r)
+                    for (int k = 0; k < PS; ++k)
+                        for (int q = 0; q < 16; ++q)
+                            for (int e = 0; e < 4; ++e)
+                                dst[(((size_t)r * PS + k) * 16 + q) * 4 + e] = W[(size_t)(row0 + r) * S + q * 4 * PS + 4 * k + e];
+            };
+            fill(img, O1, g * U, U);
+            fill(img + (size_t)U * S, O3, g * U, U);
+            fill(img + (size_t)2 * U * S, O2, g * QW, QW);
+            fill(img + (size_t)2 * U * S + (size_t)QW * S, O4, g * QW, QW);
+        }
+        auto upload = [&](float *&dst, const std::vector<float> &src) -> int {
+            if (dst) { (void)hipFree(dst); dst = nullptr; }
+            DM_TRY(h, hipMalloc(&dst, src.size() * sizeof(float)));
+            DM_TRY(h, hipMemcpy(dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+            return WRNN_OK;
+        };
+        if ((rc = upload(h->team_w, tw)) || (rc = upload(h->team_lds, tl))) return rc;
+        if (!h->mail) {
+            DM_TRY(h, hipMalloc(&h->mail, (size_t)WRNN_DM_MAIL_GRANULES * sizeof(unsigned long long)));
+            DM_TRY(h, hipMalloc(&h->ctl, 256));
+        }
+    }
     h->loaded = true;
+    return WRNN_OK;
+}
+
+int wrnn_dm_set_kernel(wrnn_dm_handle *h, int32_t kernel) {
+    if (!h) return WRNN_ERR_INVALID;
+    if (kernel < 0 || kernel > 2) return dm_fail(h, WRNN_ERR_INVALID, "kernel must be 0 (auto), 1 (single workgroup) or 2 (team)");
+    if (kernel == 2 && !wrnn_dm_team_supported(h->H, h->Q))
+        return dm_fail(h, WRNN_ERR_INVALID, "team kernel needs hidden_size in {512,640,768,896} and quantisation in {64,128,192,256}");
+    h->kernel = kernel;
     return WRNN_OK;
 }
 
@@ -230,9 +285,31 @@ int wrnn_dm_generate(wrnn_dm_handle *h, int64_t seq_len, int32_t noise_mode, uin
     WrnnDmArgs a = h->args;
     a.w = h->wdev; a.H = h->H; a.Q = h->Q; a.seq_len = seq_len; a.noise_mode = noise_mode; a.seed = seed; a.noise = noise_dev;
     a.coarse = coarse_out_dev; a.fine = fine_out_dev;
+    const bool team = h->kernel == 2 || (h->kernel == 0 && wrnn_dm_team_supported(h->H, h->Q));
+    if (team) {
+        hipStream_t s = (hipStream_t)stream;
+        DM_TRY(h, hipMemsetAsync(h->mail, 0, (size_t)WRNN_DM_MAIL_GRANULES * sizeof(unsigned long long), s));
+        DM_TRY(h, hipMemsetAsync(h->ctl, 0, 256, s));
+        WrnnDmTeamArgs ta{};
+        ta.base = a; ta.team_w = h->team_w; ta.team_lds = h->team_lds; ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->ctl + 32;
+        DM_TRY(h, wrnn_launch_dm_team(ta, s));
+        return WRNN_OK;
+    }
     (void)hipGetLastError();
     hipLaunchKernelGGL(dm_loop_kernel, dim3(1), dim3(DM_THREADS), 0, (hipStream_t)stream, a);
     DM_TRY(h, hipGetLastError());
+    return WRNN_OK;
+}
+
+/* device-side error word of the last team-kernel call (0 = ok); blocks until the stream work is done */
+int wrnn_dm_sync_status(wrnn_dm_handle *h, void *stream) {
+    if (!h) return WRNN_ERR_INVALID;
+    DM_TRY(h, hipSetDevice(h->device));
+    DM_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    if (!h->ctl) return WRNN_OK;
+    unsigned errw = 0;
+    DM_TRY(h, hipMemcpy(&errw, h->ctl + 32, sizeof(errw), hipMemcpyDeviceToHost));
+    if (errw) return dm_fail(h, WRNN_ERR_TIMEOUT, "device-side bounded spin gave up (code %u)", errw);
     return WRNN_OK;
 }
 

@@ -57,10 +57,12 @@ class WaveRNN(nn.Module):
             self._native_key = key
         return self._native
 
-    def generate(self, seq_len, *, noise_mode=_cabi.NOISE_PHILOX, seed=None, noise=None):
+    def generate(self, seq_len, *, noise_mode=_cabi.NOISE_PHILOX, seed=None, noise=None, kernel=0):
         """Returns ``(output, coarse, fine)`` like the reference (:161-165): int64 arrays of length ``seq_len``,
-        ``output = coarse * 256 + fine - 2**15`` (``combine_signal``, wavernn/utils/dsp.py:33-34)."""
+        ``output = coarse * 256 + fine - 2**15`` (``combine_signal``, wavernn/utils/dsp.py:33-34).
+        ``kernel``: 0 auto, 1 single-workgroup kernel (reference-ordered sums), 2 team kernel (32 CUs of one XCD)."""
         nat = self._native_handle()
+        nat.set_kernel(kernel)
         dev = torch.device('cuda', nat.device)
         with torch.cuda.device(dev):
             coarse = torch.empty(seq_len, dtype=torch.int32, device=dev)
