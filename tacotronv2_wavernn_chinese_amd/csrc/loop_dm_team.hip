@@ -98,9 +98,9 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
     float *hcS = hR + 2 * H;          // [S] new coarse half in S-chunk order (input of O1)
     float *hfS = hcS + S;             // [S] new fine half (input of O3)
     float *t1 = hfS + S;              // [S] relu(O1 / O3 output) (input of O2 / O4)
-    float *misc = t1 + S;             // [64]
+    float *misc = t1 + S;             // [128]: 0-2 team/rank/bail-out, 16-23 race partials, 32-95 sampling noise [parity][coarse 16 | fine 16]
     int *misc_i = (int *)misc;
-    float *imgO1 = misc + 64, *imgO3 = imgO1 + U * S, *imgO2 = imgO3 + U * S, *imgO4 = imgO2 + QW * S;
+    float *imgO1 = misc + 128, *imgO3 = imgO1 + U * S, *imgO2 = imgO3 + U * S, *imgO4 = imgO2 + QW * S;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = tid >> 4, q = tid & 15;
@@ -168,12 +168,18 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
     const float bO2 = qw < QW ? w[a.oO2b + cls] : 0.f, bO4 = qw < QW ? w[a.oO4b + cls] : 0.f;
     __syncthreads();
 
-    // -log q for class `cls` of softmax `which` (0 coarse, 1 fine) of sample ts; drawn one sample ahead
-    auto draw = [&](long ts, unsigned which) -> float {
-        if (qw >= QW || ts >= a.seq_len) return 0.f;
-        if (a.noise_mode == WRNN_NOISE_INJECTED) return -logf(a.noise[((size_t)ts * 2 + which) * Q + cls]);
-        if (a.noise_mode == WRNN_NOISE_PHILOX) return -logf(-logf(wrnn_uniform(a.seed, (uint64_t)ts, which, (uint32_t)cls)));
-        return 0.f;
+    // -log q for the workgroup's QW classes of both softmaxes of sample ts, drawn one sample ahead by the otherwise
+    // idle last wave (lanes 0..QW-1 coarse, 16..16+QW-1 fine) -> misc[32 + 32 * parity(ts) + lane]
+    auto draw = [&](long ts) {
+        if (wave != 7 || ts >= a.seq_len) return;
+        const unsigned which = (unsigned)(lane >> 4) & 1u;
+        const int c = lane & 15;
+        if (lane >= 32 || c >= QW) return;
+        const int k = g * QW + c;
+        float nz = 0.f;
+        if (a.noise_mode == WRNN_NOISE_INJECTED) nz = -logf(a.noise[((size_t)ts * 2 + which) * Q + k]);
+        else if (a.noise_mode == WRNN_NOISE_PHILOX) nz = -logf(-logf(wrnn_uniform(a.seed, (uint64_t)ts, which, (uint32_t)k)));
+        misc[32 + 32 * (int)((ts + 1) & 1) + lane] = nz;
     };
     // dot of an LDS-resident row (image [P planes][16 lanes] float4 per quarter-wave row) with an S-vector
     auto dotS = [&](const float *img, int row_in_wg, const float *vec) -> float {
@@ -207,33 +213,36 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
         return bi;
     };
 
+    // R(hidden) rows u, r, e of the own hidden unit (:116-119): evaluated as soon as the hidden state of a sample is
+    // complete (after the fine half was exchanged), i.e. under the O3 / O4 phases, for the NEXT sample
+    float ru = 0.f, rr = 0.f, re = 0.f;
+    auto r_rows = [&](const float *hin) {
+        const float4 *xp = (const float4 *)hin + q;
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const float4 x = xp[k * 16];
+            a0 = fmaf(wR[4 * k + 0], x.x, a0); a1 = fmaf(wR[4 * k + 1], x.y, a1);
+            b0 = fmaf(wR[CPL * 4 + 4 * k + 0], x.x, b0); b1 = fmaf(wR[CPL * 4 + 4 * k + 1], x.y, b1);
+            c0 = fmaf(wR[CPL * 8 + 4 * k + 0], x.x, c0); c1 = fmaf(wR[CPL * 8 + 4 * k + 1], x.y, c1);
+            a0 = fmaf(wR[4 * k + 2], x.z, a0); a1 = fmaf(wR[4 * k + 3], x.w, a1);
+            b0 = fmaf(wR[CPL * 4 + 4 * k + 2], x.z, b0); b1 = fmaf(wR[CPL * 4 + 4 * k + 3], x.w, b1);
+            c0 = fmaf(wR[CPL * 8 + 4 * k + 2], x.z, c0); c1 = fmaf(wR[CPL * 8 + 4 * k + 3], x.w, c1);
+        }
+        ru = dmt_row_sum(a0 + a1); rr = dmt_row_sum(b0 + b1); re = dmt_row_sum(c0 + c1);
+    };
+
     bool dead = false;
     int oc = 0, of = 0;                      // out_coarse = out_fine = 0 :90-91
     float hown = 0.0f;                       // this quarter-wave's hidden unit
-    float nzc = draw(0, 0u), nzf = draw(0, 1u);
+    draw(0);
+    __syncthreads();
     for (long t = 0; t < a.seq_len; ++t) {
         const unsigned epoch = (unsigned)t + 1u, par = epoch & 1u;
-        const float *hin = hR + (par ^ 1u) * H;   // hidden of the previous sample
         float *hout = hR + par * H;
         const float pc = (float)oc / 127.5f - 1.0f, pf = (float)of / 127.5f - 1.0f;   // :106-107
+        draw(t + 1);
 
-        // ---- R(hidden) rows u, r, e of the own hidden unit :116-119 ----
-        float ru = 0.f, rr = 0.f, re = 0.f;
-        if (qw < 2 * U) {
-            const float4 *xp = (const float4 *)hin + q;
-            float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const float4 x = xp[k * 16];
-                a0 = fmaf(wR[4 * k + 0], x.x, a0); a1 = fmaf(wR[4 * k + 1], x.y, a1);
-                b0 = fmaf(wR[CPL * 4 + 4 * k + 0], x.x, b0); b1 = fmaf(wR[CPL * 4 + 4 * k + 1], x.y, b1);
-                c0 = fmaf(wR[CPL * 8 + 4 * k + 0], x.x, c0); c1 = fmaf(wR[CPL * 8 + 4 * k + 1], x.y, c1);
-                a0 = fmaf(wR[4 * k + 2], x.z, a0); a1 = fmaf(wR[4 * k + 3], x.w, a1);
-                b0 = fmaf(wR[CPL * 4 + 4 * k + 2], x.z, b0); b1 = fmaf(wR[CPL * 4 + 4 * k + 3], x.w, b1);
-                c0 = fmaf(wR[CPL * 8 + 4 * k + 2], x.z, c0); c1 = fmaf(wR[CPL * 8 + 4 * k + 3], x.w, c1);
-            }
-            ru = dmt_row_sum(a0 + a1); rr = dmt_row_sum(b0 + b1); re = dmt_row_sum(c0 + c1);
-        }
         // ---- coarse gates :111-125 ----
         if (isCq) {
             const float Iu = iw[0] * pc + iw[1] * pf, Ir = iw[3] * pc + iw[4] * pf, Ie = iw[6] * pc + iw[7] * pf;
@@ -258,9 +267,8 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
         if (wave < S / 64) t1[chunk_idx<PS>(tid)] = dmt_take(mail, G_T1C + par * 512 + tid, epoch, dead, ta.err, 12u);
         __syncthreads();
         if (qw < QW) {
-            const float s = dotS(imgO2, qw, t1) + bO2 + nzc;
+            const float s = dotS(imgO2, qw, t1) + bO2 + misc[32 + 32 * par + qw];
             if (q == 0) dmt_st(mail, G_C + par * 256 + cls, epoch, s);
-            nzc = draw(t + 1, 0u);
         }
         oc = race(G_C, par, epoch, dead);                                   // Categorical(...).sample() :130-131
         if (g == 0 && tid == 0) a.coarse[t] = oc;
@@ -282,17 +290,18 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
             hfS[chunk_idx<PS>(tid)] = v;
         }
         __syncthreads();
+        if (isFq) r_rows(hout);   // idle from here on: R.h of the next sample now
         // ---- out_fine = O4(relu(O3(hidden_fine))) :148 ----
         if (isCq) {
             const float s = dotS(imgO3, qw, hfS) + bO3;
             if (q == 0) dmt_st(mail, G_T1F + par * 512 + orow, epoch, fmaxf(s, 0.0f));
+            r_rows(hout);         // under the t1 exchange
         }
         if (wave < S / 64) t1[chunk_idx<PS>(tid)] = dmt_take(mail, G_T1F + par * 512 + tid, epoch, dead, ta.err, 14u);
         __syncthreads();
         if (qw < QW) {
-            const float s = dotS(imgO4, qw, t1) + bO4 + nzf;
+            const float s = dotS(imgO4, qw, t1) + bO4 + misc[32 + 32 * par + 16 + qw];
             if (q == 0) dmt_st(mail, G_F + par * 256 + cls, epoch, s);
-            nzf = draw(t + 1, 1u);
         }
         of = race(G_F, par, epoch, dead);                                   // :150-151
         if (g == 0 && tid == 0) a.fine[t] = of;
@@ -307,7 +316,7 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
 template <int CPL>
 hipError_t launch_cpl(const WrnnDmTeamArgs &a, hipStream_t s) {
     const int H = 64 * CPL, S = H / 2, U = S / 32, QW = a.base.Q / 32;
-    const size_t lds = (size_t)(2 * H + 3 * S + 64 + 2 * U * S + 2 * QW * S) * sizeof(float);
+    const size_t lds = (size_t)(2 * H + 3 * S + 128 + 2 * U * S + 2 * QW * S) * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void *)dm_team_kernel<CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((dm_team_kernel<CPL>), dim3(256), dim3(DMT_THREADS), lds, s, a);
