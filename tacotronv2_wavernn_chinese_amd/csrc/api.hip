@@ -508,6 +508,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
             HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
             HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work
+            ta.prof = nullptr;   // phase-cycle instrumentation exists for the shipped kernel (TEAM2) only
             HIP_TRY(h, wrnn_launch_loop_team(ta, s));
         }
     } else {
@@ -529,7 +530,7 @@ int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out) {
     unsigned errw = 0;
     HIP_TRY(h, hipMemcpy(&errw, h->err_dev, sizeof(errw), hipMemcpyDeviceToHost));
     if (out) *out = h->last;
-    if (h->prof && (h->last.kernel == WRNN_KERNEL_TEAM || h->last.kernel == WRNN_KERNEL_TEAM2)) {
+    if (h->prof && h->last.kernel == WRNN_KERNEL_TEAM2) {
         unsigned long long pr[8 * 17];
         HIP_TRY(h, hipMemcpy(pr, h->prof, sizeof(pr), hipMemcpyDeviceToHost));
         const double n = (double)h->last.steps * ((h->last.rows + 7) / 8);
