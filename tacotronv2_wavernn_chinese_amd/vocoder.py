@@ -193,6 +193,14 @@ class WaveRNN(nn.Module):
                          overlap, mu_law, wave_len, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         return out
 
+    def fold_target_for_device(self, n_frames, overlap, device=None):
+        """``target`` that cuts one utterance into as many folds (:293-340) as the device has 32-CU teams (8 on an
+        MI355X), so that batched mode generates all folds of the utterance concurrently, one per XCD."""
+        dev = device if device is not None else next(self.parameters()).device
+        n = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 32)
+        total = int(n_frames) * self.hop_length
+        return max(-(-(total - int(overlap)) // n) - int(overlap), int(overlap), 1)
+
     def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law, epilogue='host',
                  **native_opts):
         """Same contract as the reference ``generate`` (:169-264), including its quirks:
@@ -202,6 +210,9 @@ class WaveRNN(nn.Module):
         (:245); the model is left in train mode (:262) and a wav is always written (:260).
         Sampling draws from a device counter RNG seeded from the global torch generator, so
         ``torch.manual_seed`` makes a call reproducible like it does for the reference.
+        ``target='auto'`` (extension, batched mode): fold length chosen so that the utterance becomes one fold per
+        XCD team of the device -- the lowest-latency way to generate a single utterance (crossfades as in the
+        reference's batched mode).
         ``epilogue='device'`` runs decode / unfold / fade-out on the GPU (tables built like NumPy builds them;
         identical output up to the host libm's ``pow``) instead of the float64 NumPy pass on the host.
         """
@@ -210,6 +221,10 @@ class WaveRNN(nn.Module):
         start = time.time()
         mels_t = torch.as_tensor(mels)
         wave_len = (mels_t.size(-1) - 1) * self.hop_length
+        if isinstance(target, str):
+            if target != 'auto':
+                raise ValueError(f"target must be an int or 'auto', got {target!r}")
+            target = self.fold_target_for_device(mels_t.size(-1), overlap)
         if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) == _cabi.NOISE_PHILOX:
             native_opts['seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
         res = self.generate_raw(mels_t, batched, target, overlap, **native_opts)
