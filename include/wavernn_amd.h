@@ -156,6 +156,12 @@ int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int32_t *label
                   int32_t batched, int32_t target, int32_t overlap, int32_t mu_law, int64_t wave_len,
                   double *wave_out_dev, void *stream);
 
+/* Host-only helper (no device): the float64 tables wrnn_epilogue gathers from, built in NumPy's evaluation order --
+ * dec[n_classes] (decode_mu_law of 2k/(n_classes-1)-1, dsp.py:98-103), fade_in/fade_out[overlap] (:374-385, may be
+ * NULL when overlap == 0), tail[20*hop] (np.linspace(1, 0, 20*hop_length), :256).  Caller-allocated. */
+int wrnn_epilogue_tables(int32_t n_classes, int32_t overlap, int32_t hop, double *dec, double *fade_in, double *fade_out,
+                         double *tail);
+
 /* Blocks until the last wrnn_generate on this handle finished, then reports
  * HIP-event timings and any device-side error (WRNN_ERR_TIMEOUT). */
 int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out);

@@ -26,9 +26,22 @@ ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN
 # every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
-                    'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue',
+                    'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_tables',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
                     'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
+
+
+def epilogue_tables(n_classes: int, overlap: int, hop: int):
+    """Host-only: (dec, fade_in, fade_out, tail) float64 arrays as ``wrnn_epilogue`` uses them."""
+    lib = load_library()
+    dec = np.empty(n_classes, np.float64)
+    fin, fout = np.empty(max(overlap, 0), np.float64), np.empty(max(overlap, 0), np.float64)
+    tail = np.empty(20 * hop, np.float64)
+    rc = lib.wrnn_epilogue_tables(n_classes, overlap, hop, dec.ctypes.data, fin.ctypes.data if overlap else None,
+                                  fout.ctypes.data if overlap else None, tail.ctypes.data)
+    if rc != 0:
+        raise WrnnError(rc, 'wrnn_epilogue_tables: invalid arguments')
+    return dec, fin, fout, tail
 
 
 class WrnnError(RuntimeError):
@@ -111,6 +124,8 @@ def load_library() -> C.CDLL:
     lib.wrnn_epilogue.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                   vp, vp]
     lib.wrnn_epilogue.restype = C.c_int
+    lib.wrnn_epilogue_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    lib.wrnn_epilogue_tables.restype = C.c_int
     lib.wrnn_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.wrnn_last_timing.restype = C.c_int
     lib.wrnn_n_classes.argtypes = [vp]

@@ -59,6 +59,34 @@ void np_linspace(double start, double stop, long num, double *y) {
 
 }  // namespace
 
+// Host only (no device needed): the float64 tables of the epilogue, in NumPy's evaluation order.
+//   dec[k], k < n_classes : decode_mu_law of the fp32 value 2k/(n_classes-1) - 1 the loop feeds back   (dsp.py:98-103, :235)
+//   fade_in / fade_out [overlap] : the equal-power crossfade of xfade_and_unfold                         (:374-385)
+//   tail [20 * hop] : np.linspace(1, 0, 20 * hop_length)                                               (:256)
+extern "C" int wrnn_epilogue_tables(int32_t n_classes, int32_t overlap, int32_t hop, double *dec, double *fade_in,
+                                    double *fade_out, double *tail) {
+    if (n_classes < 2 || overlap < 0 || hop < 1 || !dec || !tail || (overlap > 0 && (!fade_in || !fade_out))) return WRNN_ERR_INVALID;
+    const double mu = (double)(n_classes - 1);
+    for (int k = 0; k < n_classes; ++k) {
+        const float xf = 2.0f * (float)k / ((float)n_classes - 1.0f) - 1.0f;   // the fp32 value the loop feeds back (:235)
+        const double y = (double)xf;
+        const double sg = y > 0.0 ? 1.0 : (y < 0.0 ? -1.0 : 0.0);
+        dec[k] = sg / mu * (std::pow(1.0 + mu, std::fabs(y)) - 1.0);           // dsp.py:98-103
+    }
+    if (overlap > 0) {
+        const long silence = overlap / 2, fl = overlap - silence;              // (:374-375)
+        std::vector<double> t((size_t)fl);
+        np_linspace(-1.0, 1.0, fl, t.data());
+        for (long k = 0; k < silence; ++k) { fade_in[k] = 0.0; fade_out[k] = 1.0; }
+        for (long k = 0; k < fl; ++k) {
+            fade_in[silence + k] = std::sqrt(0.5 * (1.0 + t[(size_t)k]));      // (:378-379)
+            fade_out[silence + k] = std::sqrt(0.5 * (1.0 - t[(size_t)k]));
+        }
+    }
+    np_linspace(1.0, 0.0, 20L * hop, tail);                                    // (:256)
+    return WRNN_OK;
+}
+
 extern "C" int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int32_t *labels_dev, int32_t rows, int64_t steps,
                              int32_t batched, int32_t target, int32_t overlap, int32_t mu_law, int64_t wave_len,
                              double *wave_out_dev, void *stream) {
@@ -86,24 +114,7 @@ extern "C" int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int
     if (h->epi_overlap != ov || !h->epi_tab) {
         std::vector<double> tab((size_t)NC + 2 * (size_t)ov + (size_t)tail_len, 0.0);
         double *dec = tab.data(), *fin = dec + NC, *fout = fin + ov, *tail = fout + ov;
-        const double mu = (double)(NC - 1);
-        for (int k = 0; k < NC; ++k) {
-            const float xf = 2.0f * (float)k / ((float)NC - 1.0f) - 1.0f;    // the fp32 value the loop feeds back (:235)
-            const double y = (double)xf;
-            const double sg = y > 0.0 ? 1.0 : (y < 0.0 ? -1.0 : 0.0);
-            dec[k] = sg / mu * (std::pow(1.0 + mu, std::fabs(y)) - 1.0);     // dsp.py:98-103
-        }
-        if (ov > 0) {
-            const long silence = ov / 2, fl = ov - silence;                   // (:374-375)
-            std::vector<double> t((size_t)fl);
-            np_linspace(-1.0, 1.0, fl, t.data());
-            for (long k = 0; k < silence; ++k) { fin[k] = 0.0; fout[k] = 1.0; }
-            for (long k = 0; k < fl; ++k) {
-                fin[silence + k] = std::sqrt(0.5 * (1.0 + t[(size_t)k]));    // (:378-379)
-                fout[silence + k] = std::sqrt(0.5 * (1.0 - t[(size_t)k]));
-            }
-        }
-        np_linspace(1.0, 0.0, tail_len, tail);                                // (:256)
+        wrnn_epilogue_tables(NC, (int32_t)ov, d.HOP, dec, fin, fout, tail);
         if (h->epi_tab) { (void)hipFree(h->epi_tab); h->epi_tab = nullptr; }
         if (hipMalloc(&h->epi_tab, tab.size() * sizeof(double)) != hipSuccess) return fail(WRNN_ERR_HIP, "wrnn_epilogue: hipMalloc failed");
         if (hipMemcpy(h->epi_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)

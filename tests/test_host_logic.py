@@ -134,3 +134,24 @@ def test_gen_from_file_validates_like_the_reference(tmp_path):
     # (1, n_mels, T) tensor, reference file-name pattern (wavernn_gen.py:35-39), hp.mu_law
     assert "(1, 80, 33)" in calls[0] and 'ok_gen_NOT_BATCHED_step=123k.wav' in calls[0] and calls[0].endswith('True')
     assert 'ok_gen_batched_target2000_overlap200_step=123k.wav' in calls[1]
+
+
+def test_epilogue_tables_follow_numpy():
+    """The float64 tables behind wrnn_epilogue (built on the host, no device needed) against NumPy evaluated the
+    way fatchord_version.py:256,374-385 and dsp.py:98-103 evaluate them: linspace and sqrt bit-for-bit, the
+    mu-law decode (pow) within 2 ulp."""
+    from oracle import oracle as orc
+    from tacotronv2_wavernn_chinese_amd._cabi import epilogue_tables
+    for n_classes, overlap, hop in ((1024, 550, 275), (512, 101, 200), (1024, 0, 275)):
+        dec, fin, fout, tail = epilogue_tables(n_classes, overlap, hop)
+        np.testing.assert_array_equal(tail, np.linspace(1, 0, 20 * hop))
+        if overlap:
+            silence = overlap // 2
+            t = np.linspace(-1, 1, overlap - silence, dtype=np.float64)
+            np.testing.assert_array_equal(fin, np.concatenate([np.zeros(silence), np.sqrt(0.5 * (1 + t))]))
+            np.testing.assert_array_equal(fout, np.concatenate([np.ones(silence), np.sqrt(0.5 * (1 - t))]))
+        k = np.arange(n_classes, dtype=np.float32)
+        fed_back = (np.float32(2.0) * k / np.float32(n_classes - 1.0) - np.float32(1.0)).astype(np.float64)   # :235
+        want = orc.decode_mu_law(fed_back, n_classes)
+        np.testing.assert_allclose(dec, want, rtol=4.5e-16, atol=1e-18)   # pow(); near 0 the "- 1" cancels
+        assert dec[0] == -1.0 or abs(dec[0] + 1.0) < 1e-15
