@@ -77,6 +77,9 @@ __device__ __forceinline__ float dmt_wave_max(float v) {   // max over 64 lanes,
     return v;
 }
 
+__device__ __forceinline__ float dmt_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float dmt_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+
 constexpr unsigned G_HC = 0, G_T1C = 1024, G_HF = 2048, G_T1F = 3072, G_C = 4096, G_F = 4608;   // x2 parities each
 
 // A vector of N = 64*P floats in LDS, chunked for 16 lanes of P float4 each: element j (chunk q = j / (4P), float4 k
@@ -246,9 +249,9 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
         // ---- coarse gates :111-125 ----
         if (isCq) {
             const float Iu = iw[0] * pc + iw[1] * pf, Ir = iw[3] * pc + iw[4] * pf, Ie = iw[6] * pc + iw[7] * pf;
-            const float u = 1.0f / (1.0f + expf(-(ru + Iu + bu)));
-            const float r = 1.0f / (1.0f + expf(-(rr + Ir + br)));
-            const float e = tanhf(r * re + Ie + be);
+            const float u = dmt_sigmoid(ru + Iu + bu);
+            const float r = dmt_sigmoid(rr + Ir + br);
+            const float e = dmt_tanh(r * re + Ie + be);
             hown = u * hown + (1.0f - u) * e;
             if (q == 0) dmt_st(mail, G_HC + par * 512 + hi, epoch, hown);
         }
@@ -278,9 +281,9 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
             const float Iu = iw[0] * pc + iw[1] * pf + iw[2] * cp;
             const float Ir = iw[3] * pc + iw[4] * pf + iw[5] * cp;
             const float Ie = iw[6] * pc + iw[7] * pf + iw[8] * cp;
-            const float u = 1.0f / (1.0f + expf(-(ru + Iu + bu)));
-            const float r = 1.0f / (1.0f + expf(-(rr + Ir + br)));
-            const float e = tanhf(r * re + Ie + be);
+            const float u = dmt_sigmoid(ru + Iu + bu);
+            const float r = dmt_sigmoid(rr + Ir + br);
+            const float e = dmt_tanh(r * re + Ie + be);
             hown = u * hown + (1.0f - u) * e;
             if (q == 0) dmt_st(mail, G_HF + par * 512 + (hi - S), epoch, hown);
         }

@@ -591,8 +591,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                         const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max(v)), 63));
                         const u64 ball = __ballot(v == mx);
                         const int km = (int)__builtin_ctzll(ball ? ball : 1ull);
-                        const float mean = __shfl(mylg, nr + km, 64);
-                        const float ls = fmaxf(__shfl(mylg, 2 * nr + km, 64), -32.23619130191664f);
+                        // km is wave-uniform (from the ballot): v_readlane instead of a ds_bpermute round trip
+                        const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylg), nr + km));
+                        const float ls = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylg), 2 * nr + km)), -32.23619130191664f);
                         float xs = mean + expf(ls) * misc_f[32 + 16 * par + nr];
                         xs = fminf(fmaxf(xs, -1.0f), 1.0f);
                         if (lane == 0) {
