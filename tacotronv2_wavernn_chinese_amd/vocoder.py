@@ -63,6 +63,12 @@ def _make_upsample(feat_dims, upsample_scales, compute_dims, res_blocks, res_out
     return up
 
 
+def fold_target(total_len: int, overlap: int, n_folds: int) -> int:
+    """Smallest ``target`` for which ``fold_with_overlap`` (:293-340) cuts ``total_len`` samples into at most
+    ``n_folds`` folds: ceil((total_len - overlap) / n_folds) - overlap, never below ``overlap``."""
+    return max(-(-(int(total_len) - int(overlap)) // int(n_folds)) - int(overlap), int(overlap), 1)
+
+
 class WaveRNN(nn.Module):
     def __init__(self, rnn_dims, fc_dims, bits, pad, upsample_factors,
                  feat_dims, compute_dims, res_out_dims, res_blocks,
@@ -198,8 +204,7 @@ class WaveRNN(nn.Module):
         MI355X), so that batched mode generates all folds of the utterance concurrently, one per XCD."""
         dev = device if device is not None else next(self.parameters()).device
         n = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 32)
-        total = int(n_frames) * self.hop_length
-        return max(-(-(total - int(overlap)) // n) - int(overlap), int(overlap), 1)
+        return fold_target(int(n_frames) * self.hop_length, int(overlap), n)
 
     def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law, epilogue='host',
                  **native_opts):

@@ -155,3 +155,20 @@ def test_epilogue_tables_follow_numpy():
         want = orc.decode_mu_law(fed_back, n_classes)
         np.testing.assert_allclose(dec, want, rtol=4.5e-16, atol=1e-18)   # pow(); near 0 the "- 1" cancels
         assert dec[0] == -1.0 or abs(dec[0] + 1.0) < 1e-15
+
+
+def test_fold_target_gives_at_most_one_fold_per_team():
+    """target='auto': the reference's fold count (:319-325) for the chosen target never exceeds the number of
+    teams, and uses all of them once the clip is long enough."""
+    from tacotronv2_wavernn_chinese_amd.vocoder import fold_target
+    for n in (8, 4, 1):
+        for T in (21, 30, 61, 401, 1200):
+            for overlap in (100, 550):
+                L = T * 275
+                target = fold_target(L, overlap, n)
+                num_folds, remaining = divmod(L - overlap, target + overlap)   # :319-322
+                if remaining != 0:
+                    num_folds += 1                                             # :324-325
+                assert 1 <= num_folds <= n, (n, T, overlap, target, num_folds)
+                if L >= n * 3 * overlap:
+                    assert num_folds == n
