@@ -306,6 +306,15 @@ def test_many_rows_are_scheduled_independently(kernel):
     for i in range(3, 19):
         np.testing.assert_array_equal(lab[i], lab[i % 3])
     assert not np.array_equal(lab[0], lab[1])
+    if kernel == 'team2':
+        # several rows per team AND several segment launches per row: every (row, segment) hands its own state over
+        os.environ['WRNN_TEAM2_SEGMENT'] = '160'
+        try:
+            res2 = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_ARGMAX)
+        finally:
+            del os.environ['WRNN_TEAM2_SEGMENT']
+        assert m.last_timing['launches'] > 30
+        np.testing.assert_array_equal(res2['labels'].cpu().numpy(), lab)
     om = orc.OracleModel(fx['state_dict'], fast=True)
     cm, ca = om.conditioning(base[:1])
     ref = om.loop(cm, ca, orc.NOISE_ARGMAX)
