@@ -1,29 +1,40 @@
 """bench.py -- the driver's benchmark contract for the WaveRNN mel->wav hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,4,3}]
 
-One "step" = one pass of the hot path over one batch of synthetic input: the
-prologue + per-sample loop for ONE ~5 s utterance per GPU (BASELINE.json
-configs[1]: 1xMI355X, batch=1, 80-dim mel, T=401 frames -> 110 275 loop steps,
-RAW 10-bit, hop 275), inputs resident in HBM when the timed region starts.
-metric = audio ksamples/s (all loop steps counted, like the reference's own
-"Gen Rate" meter, fatchord_version.py:267-271), whole job over all N GPUs
-(one independent utterance per GPU per step: weak scaling, no data-path
-collective -- utterances are independent).
+`python bench.py --gpus N` launches its own N ranks (re-exec under torch.distributed.run, one rank per GPU, RCCL);
+started under torch.distributed.run it uses the ranks it is given.
+
+One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
+  --config 1 (default; BASELINE.json configs[1], the config the metric is quoted on): ONE ~5 s utterance per GPU,
+             B=1, mel 80x401 -> 110 275 loop steps, RAW 10-bit, hop 275: prologue + per-sample loop (latency kernel,
+             one XCD team) + float64 epilogue on the device;
+  --config 2 (configs[2]): 64 utterances of that shape per GPU in one call (batch kernel: 8 rows per XCD team in lock-step
+             on the matrix cores);
+  --config 4 (configs[4]): MOL 9-bit, 32 utterances per GPU (batch kernel, 4 rows per team);
+  --config 3 (configs[3]): throughput mode, 64 utterances per GPU (512 over 8 GPUs): rank 0 owns all clips, scatters the
+             mels over RCCL, every rank generates its 64, the samples are gathered back on rank 0 -- the only collectives
+             of the path (utterances are independent: SURVEY.md 8e); scatter + gather are inside the timed region.
+metric = audio ksamples/s (all loop steps of all rows counted, like the reference's own "Gen Rate" meter,
+fatchord_version.py:267-271), whole job over all N GPUs; weak scaling (the per-GPU batch is fixed).
 
 Extra objects on the JSON line:
-  roofline     -- memory-bound roofline of the batch-1 loop kernel: ALGORITHMIC bytes
-                  (17 371 136 B of fp32 loop parameters + 836 B conditioning/sample per
-                  step) x steps per launch / the loop kernel's average launch duration
-                  (HIP events recorded by the library on the launch stream) vs 8 TB/s.
-  cpu_baseline -- the CPU restatement (oracle/, "port") timed on this box's host cores on
-                  a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      -- ALGORITHMIC bytes (weights once per step for the whole batch + 836 B conditioning/sample, SURVEY.md
+                   8d) or FLOPs (8 668 160 per sample RAW) x steps per launch / the loop kernel's average launch duration
+                   (HIP events recorded by the library on the launch stream), against the bound SURVEY 8d names for the
+                   batch size: HBM 8 TB/s for B=1 and MOL B=32, the fp32 matrix/vector peak 157.3 TFLOP/s for B=64.
+  cpu_baseline  -- the CPU restatement (oracle/, "port") timed on this box's host cores on BASELINE configs[0]'s clip
+                   (80x200, 55 000 steps), rank 0 at N=1 only;
+  cpu_reference -- the UNMODIFIED reference generate() (PyTorch CPU) timed by oracle/time_reference.py where
+                   /root/reference exists (the build container; `where` says so) -- the GPU box has no reference tree.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,17 +47,22 @@ if ROOT not in sys.path:
 T_FRAMES = 401                      # ~5 s clip: wave_len = 400 * 275 = 110 000 samples = 4.989 s
 HOP = 275
 SAMPLE_RATE = 22050
-BYTES_PER_SAMPLE_B1 = 17_371_136 + 836   # W + (C + O) at B = 1
-FLOP_PER_SAMPLE = 8_668_160
+W_BYTES = {'RAW': 17_371_136, 'MOL': 15_331_448}       # fp32 loop parameters
+COND_BYTES = 836                                        # conditioning row + sample per loop step
+FLOP_PER_SAMPLE = {'RAW': 8_668_160, 'MOL': 7_650_304}
 HBM_PEAK = 8.0e12                   # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of the loop kernel over ONE utterance of the T=401 workload from the PMC passes in
-# profiles/r01_rocprofv3_bench_team*.txt (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE)
-TRAFFIC_BYTES_PER_UTTERANCE = {2: int((20082.2 * 2 + 1309.6) * 1024),           # team : weights once + per-frame records (1 launch)
-                               3: int((542750.375 * 2 + 24372.96875) * 1024)}   # team2: 14 launches: weights 14x + the 8 KB/step stream + state
+F32_PEAK = 157.3e12                 # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
+           2: dict(mode='RAW', bits=10, batch=64, name='configs[2]'),
+           4: dict(mode='MOL', bits=9, batch=32, name='configs[4]'),
+           3: dict(mode='RAW', bits=10, batch=64, name='configs[3]')}
+# HBM bytes of the loop kernel per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
+# correction of MI355X_MICROARCH.md + WRITE_SIZE), keyed by (config, kernel); absent = not measured
+TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): int((542750.375 * 2 + 24372.96875) * 1024) // 14}
 
 
-def cpu_baseline(frames: int = 61, max_threads: int = 16) -> dict:
-    """Oracle (C port of the reference algorithm) on the host cores, bounded sample."""
+def cpu_baseline(frames: int = 200, max_threads: int = 16) -> dict:
+    """Oracle (C port of the reference algorithm) on the host cores: BASELINE configs[0]'s clip (one 80x200 mel)."""
     from oracle import oracle as orc
     from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
     sd = make_state_dict(0, variant='peaky')
@@ -62,8 +78,42 @@ def cpu_baseline(frames: int = 61, max_threads: int = 16) -> dict:
     om.loop(cm, ca, orc.NOISE_EXPO, q, num_threads=threads)
     t2 = time.perf_counter()
     return dict(value=round(L / (t2 - t1) / 1000.0, 3), unit='ksamples/s', cores=threads, kind='port',
-                sample=f'C restatement of generate() (oracle/wavernn_oracle.c, OpenMP+AVX2), B=1, mel 80x{frames} '
+                sample=f'BASELINE configs[0]: C restatement of generate() (oracle/wavernn_oracle.c, OpenMP+AVX2), B=1, mel 80x{frames} '
                        f'({L} loop steps, {t2 - t1:.1f} s loop + {t1 - t0:.1f} s prologue/noise), RAW 10-bit, injected Exp(1) noise')
+
+
+def cpu_reference() -> dict | None:
+    """The unmodified reference's own timing (oracle/time_reference.py, run where /root/reference exists)."""
+    path = os.path.join(ROOT, 'profiles', 'cpu_reference_container.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    runs = {(r['frames'], r['threads']): r for r in rec['runs']}
+    allc, one = runs.get((200, rec['nproc'])), runs.get((200, 1))
+    if not allc:
+        return None
+    out = dict(value=allc['ksamples_per_s'], unit='ksamples/s', cores=rec['nproc'], kind='reference',
+               one_thread=one['ksamples_per_s'] if one else None, where=rec['where'], cpu=rec['cpu'], measured=rec['date'],
+               sample=f'BASELINE configs[0]: {rec["what"]}; mel 80x200 ({allc["loop_steps"]} loop steps) in {allc["seconds"]} s on '
+                      f'{rec["nproc"]} threads' + (f', {one["seconds"]} s on 1 thread' if one else ''))
+    big = runs.get((401, rec['nproc']))
+    if big:
+        out['config1_clip'] = dict(frames=401, ksamples_per_s=big['ksamples_per_s'], seconds=big['seconds'])
+    return out
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no ranks around it: become the launcher."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main() -> int:
@@ -71,10 +121,21 @@ def main() -> int:
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument('--frames', type=int, default=T_FRAMES)
-    ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'team', 'simple'])
+    ap.add_argument('--batch', type=int, default=0, help='rows per GPU (default: the config\'s)')
+    ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'batch', 'simple'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return self_launch(args)
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+        return 2
 
     import torch
     import torch.distributed as dist
@@ -82,43 +143,59 @@ def main() -> int:
     from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_mels, make_state_dict
     from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})',
-              file=sys.stderr)
-        return 2
+    if not torch.cuda.is_available():
+        print('bench.py: no HIP device visible (the hot path has no CPU fallback)', file=sys.stderr)
+        return 3
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
 
+    cfg = CONFIGS[args.config]
+    mode, B = cfg['mode'], (args.batch or cfg['batch'])
     # synthetic weights of the reference architecture + synthetic mel (no checkpoint ships: .MISSING_LARGE_BLOBS)
-    sd = make_state_dict(0, variant='peaky')
-    model = WaveRNN(**DEFAULT_DIMS, mode='RAW')
+    sd = make_state_dict(0, mode=mode, variant='peaky' if mode == 'RAW' else 'default', bits=cfg['bits'])
+    dims = dict(DEFAULT_DIMS)
+    dims['bits'] = cfg['bits']
+    model = WaveRNN(**dims, mode=mode)
     model.verbose = False
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model.to(dev)
-    model.kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'team': _cabi.KERNEL_TEAM, 'simple': _cabi.KERNEL_SIMPLE}[args.kernel]
+    model.kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[args.kernel]
     T = args.frames
-    mels = torch.from_numpy(make_mels(1000 + rank, 1, T)).to(dev)   # resident in HBM before timing
+    scatter = args.config == 3
+    if scatter and rank == 0:
+        all_mels = torch.from_numpy(make_mels(1000, world * B, T)).to(dev)   # rank 0 owns the whole job, resident in HBM
+        mels = torch.empty((B, 80, T), dtype=torch.float32, device=dev)
+    elif scatter:
+        all_mels, mels = None, torch.empty((B, 80, T), dtype=torch.float32, device=dev)
+    else:
+        mels = torch.from_numpy(make_mels(1000 + rank, B, T)).to(dev)       # resident in HBM before timing
     nat = model.native()
-    rows, L = nat.plan(1, T, False, 11000, 550)
+    rows, L = nat.plan(B, T, False, 11000, 550)
     samples = torch.empty((rows, L), dtype=torch.float32, device=dev)
     labels = torch.empty((rows, L), dtype=torch.int32, device=dev)
     wave_len = (T - 1) * HOP
-    wave = torch.empty((wave_len,), dtype=torch.float64, device=dev)   # what generate() returns (:264)
+    wave = torch.empty((rows, wave_len), dtype=torch.float64, device=dev)   # what generate() returns (:264), per utterance
+    gathered = [torch.empty((rows, wave_len), dtype=torch.float64, device=dev) for _ in range(world)] if (scatter and rank == 0) else None
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def one_step(i: int):
-        nat.generate(mels.data_ptr(), 1, T, False, 11000, 550, labels_ptr=labels.data_ptr(),
+        if scatter and world > 1:
+            dist.scatter(mels, list(all_mels.view(world, B, 80, T).unbind(0)) if rank == 0 else None, src=0)
+        elif scatter:
+            mels.copy_(all_mels)
+        nat.generate(mels.data_ptr(), B, T, False, 11000, 550, labels_ptr=labels.data_ptr(),
                      samples_ptr=samples.data_ptr(), stream=stream, noise_mode=_cabi.NOISE_PHILOX,
                      seed=0xC0FFEE + 7919 * i + rank, kernel=model.kernel)
-        # float64 tail of generate() (mu-law decode, trim, fade-out) on the device: the step ends with the waveform
-        nat.epilogue(samples.data_ptr(), labels.data_ptr(), rows, L, False, 11000, 550, True, wave_len,
-                     wave.data_ptr(), stream)
+        # float64 tail of generate() (mu-law decode, trim, fade-out) on the device, for every utterance of the batch
+        # (wrnn_epilogue finishes one unbatched utterance per call, like :253)
+        for r in range(rows):
+            nat.epilogue(samples.data_ptr() + 4 * r * L, labels.data_ptr() + 4 * r * L, 1, L, False, 11000, 550, mode == 'RAW',
+                         wave_len, wave.data_ptr() + 8 * r * wave_len, stream)
+        if scatter and world > 1:
+            dist.gather(wave, gathered, dst=0)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -130,6 +207,7 @@ def main() -> int:
         one_step(-1 - i)
     barrier()
     loop_ms, pro_ms = [], []
+    tm = None
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
@@ -138,7 +216,7 @@ def main() -> int:
         pro_ms.append(tm['prologue_ms'])
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ran = tm['kernel']
+    kernel_ran = tm['kernel'] if tm else 0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -148,31 +226,43 @@ def main() -> int:
         total_samples = world * args.steps * rows * L
         value = total_samples / dt / 1000.0
         audio_s = (T - 1) * HOP / SAMPLE_RATE
-        k_ms = float(np.mean(loop_ms))
-        launches = max(1, int(tm.get('launches', 1)))    # segments one utterance is generated in
-        achieved = (BYTES_PER_SAMPLE_B1 * rows * L / launches) / (k_ms * 1e-3 / launches)
-        traffic = TRAFFIC_BYTES_PER_UTTERANCE.get(kernel_ran) if T == T_FRAMES else None
+        k_ms = float(np.mean(loop_ms)) if loop_ms else float('nan')
+        launches = max(1, int(tm.get('launches', 1))) if tm else 1   # segments an utterance is generated in
+        bytes_per_sample = W_BYTES[mode] / rows + COND_BYTES
+        bw_bound = HBM_PEAK / bytes_per_sample
+        fl_bound = F32_PEAK / FLOP_PER_SAMPLE[mode]
+        rate = rows * L / (k_ms * 1e-3)                              # row-steps per second of the loop kernel alone
+        if fl_bound < bw_bound:
+            roof = {'bound': 'mfma', 'achieved': round(rate * FLOP_PER_SAMPLE[mode] / 1e12, 3), 'peak': F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+                    'frac': round(rate / fl_bound, 4)}
+            roof_note = (f'achieved = {FLOP_PER_SAMPLE[mode]} FLOP/sample x {rows} rows x steps per launch / loop-kernel launch duration; '
+                         f'bound = fp32 matrix/vector peak (B={rows}: {fl_bound / 1e6:.1f} Msamples/s; the HBM bound would be {bw_bound / 1e6:.1f})')
+        else:
+            roof = {'bound': 'hbm', 'achieved': round(rate * bytes_per_sample / 1e9, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'frac': round(rate / bw_bound, 4)}
+            roof_note = (f'achieved = algorithmic bytes ({bytes_per_sample:.0f} B/sample at B={rows}: weights once per step for the batch + 836 B) '
+                         f'x steps per launch / average loop-kernel launch duration (HIP events around the {launches} launch(es) of one call); '
+                         'the weights are register/LDS resident, so the kernel is latency/issue-bound, not HBM-bound: traffic = measured '
+                         'HBM bytes per launch where a PMC pass exists (profiles/)')
+        roof['traffic'] = TRAFFIC_BYTES_PER_LAUNCH.get((args.config, kernel_ran)) if T == T_FRAMES else None
+        roof['note'] = roof_note
         out = {
-            'metric': 'audio ksamples/sec (22.05 kHz, 10-bit RAW WaveRNN, batch=1 per GPU)',
+            'metric': f'audio ksamples/sec (22.05 kHz, {"10-bit RAW" if mode == "RAW" else "9-bit MOL"} WaveRNN, batch={B} per GPU)',
             'value': round(value, 3), 'unit': 'ksamples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: 1 utterance per GPU per step, B=1, mel 80x{T} '
-                                   f'({L} loop steps = {audio_s:.3f} s audio), RAW 10-bit, hop 275, prologue + loop + float64 epilogue on the device, '
-                                   'Philox sampling noise, seeded synthetic weights (fc3 x128)',
-                       'kernel': {1: 'simple', 2: 'team', 3: 'team2'}.get(kernel_ran, str(kernel_ran)),
-                       'real_time_factor': round((dt / args.steps) / audio_s, 4),
-                       'times_real_time': round(audio_s / (dt / args.steps), 2),
+            'config': {'workload': f'BASELINE {cfg["name"]}: {B} utterance(s) per GPU per step, mel 80x{T} '
+                                   f'({L} loop steps = {audio_s:.3f} s audio each), {"RAW 10-bit" if mode == "RAW" else "MOL 9-bit"}, hop 275, '
+                                   'prologue + loop + float64 epilogue on the device, Philox sampling noise, seeded synthetic weights'
+                                   + (', mels scattered from / waveforms gathered on rank 0 over RCCL inside the timed region' if scatter else ''),
+                       'kernel': _cabi.KERNEL_NAMES.get(kernel_ran, str(kernel_ran)),
+                       'real_time_factor': round((dt / args.steps) / (audio_s * rows), 5),
+                       'times_real_time': round(audio_s * rows / (dt / args.steps), 2),
                        'prologue_ms': round(float(np.mean(pro_ms)), 3), 'loop_kernel_ms': round(k_ms, 3),
-                       'loop_launches_per_utterance': launches, 'loop_launch_avg_ms': round(k_ms / launches, 3),
-                       'parallelism': f'utterance-parallel x{world} (no data-path collective)'},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved / 1e9, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK, 4), 'traffic': None if traffic is None else traffic // launches,
-                         'note': 'achieved = algorithmic bytes (17 371 972 B/sample at B=1) x steps per launch / average loop-kernel '
-                                 'launch duration (an utterance is generated in loop_launches_per_utterance launches; HIP events '
-                                 'around the whole sequence / launches); traffic = measured HBM bytes per launch (PMC passes, '
-                                 'profiles/): the weights are register/LDS resident, so the kernel is latency/issue-bound, not '
-                                 'HBM-bound'},
+                       'loop_launches_per_call': launches, 'loop_launch_avg_ms': round(k_ms / launches, 3),
+                       'us_per_step': round(k_ms * 1e3 / L, 4),
+                       'parallelism': f'utterance-parallel x{world} (no data-path collective' + (' but the scatter/gather of clips)' if scatter else ')')},
+            'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -180,6 +270,9 @@ def main() -> int:
             except Exception as e:  # the baseline must never sink the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'ksamples/s', 'cores': 0, 'kind': 'port',
                                        'sample': f'failed: {e!r}'}
+            ref = cpu_reference()
+            if ref:
+                out['cpu_reference'] = ref
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

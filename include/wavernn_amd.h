@@ -16,7 +16,13 @@
  * scratch; one handle per device; a handle is not thread-safe, distinct
  * handles are independent.  All `*_dev` pointers are device (HBM) pointers on
  * the handle's device; everything is enqueued on the caller's `stream`
- * (a hipStream_t passed as void*) and is asynchronous unless stated.
+ * (a hipStream_t passed as void*) and is asynchronous unless stated
+ * (wrnn_last_timing and wrnn_dm_sync_status wait; nothing else does).
+ *
+ * The TEAM2 / BATCH kernels keep n_teams * 32 workgroups spinning on each other inside one launch, so all of them
+ * must be resident at once (one per CU): wrnn_create establishes that with the runtime's occupancy query and the CU
+ * count; on a device where it does not hold (partitioned / shared GPU) AUTO uses the SIMPLE kernel and an explicit
+ * request for a team kernel fails with WRNN_ERR_INVALID.  Do not run two team-kernel calls concurrently on one device.
  */
 #ifndef WAVERNN_AMD_H
 #define WAVERNN_AMD_H
@@ -27,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 2
+#define WRNN_ABI_VERSION 3
 
 /* mode: fatchord_version.py:98-103 */
 #define WRNN_MODE_RAW 0 /* softmax over 2**bits classes */
@@ -40,10 +46,12 @@ extern "C" {
 #define WRNN_NOISE_ARGMAX 2   /* RAW only: greedy (q == 1) */
 
 /* which device implementation runs the per-sample loop */
-#define WRNN_KERNEL_AUTO 0
-#define WRNN_KERNEL_SIMPLE 1 /* one workgroup per row, weights streamed from L2/HBM */
-#define WRNN_KERNEL_TEAM 2   /* one XCD-resident team per row, weights on chip, 4 waves per workgroup */
-#define WRNN_KERNEL_TEAM2 3  /* same team, 8 waves per workgroup specialised into critical / shadow roles */
+#define WRNN_KERNEL_AUTO 0   /* rows <= XCD teams: TEAM2 (latency); more rows: BATCH (throughput); SIMPLE when the team
+                              * kernels cannot run on this device / configuration */
+#define WRNN_KERNEL_SIMPLE 1 /* one workgroup per row, weights streamed from L2/HBM; any shape */
+/* 2 was the 4-wave team kernel of ABI 2 (retired) */
+#define WRNN_KERNEL_TEAM2 3  /* one XCD-resident 32-workgroup team per row, weights on chip, critical / shadow wave roles */
+#define WRNN_KERNEL_BATCH 4  /* one team per 4 or 8 rows in lock-step on the matrix cores (v_mfma_f32_4x4x1) */
 
 /* tensor dtypes accepted by wrnn_load_weights */
 #define WRNN_DTYPE_F32 0
@@ -118,10 +126,11 @@ typedef struct wrnn_timing {
 /* replaces WaveRNN.__init__ (fatchord_version.py:93-129) */
 int wrnn_create(const wrnn_config *cfg, wrnn_handle **out);
 
-/* replaces WaveRNN.load / load_state_dict (fatchord_version.py:414-417).
- * strict != 0: every parameter the path needs must be present.
- * Unknown keys (e.g. optimizer leftovers) are ignored like strict=False. */
-int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n, int32_t strict);
+/* replaces WaveRNN.load / load_state_dict (fatchord_version.py:414-417).  Every parameter the path reads must be
+ * present with the reference's dtype and shape (WRNN_ERR_MISSING_KEY / WRNN_ERR_INVALID otherwise); keys the path does
+ * not read (step, num_batches_tracked, optimizer leftovers) are ignored.  The reference's strict=False tolerance for
+ * missing keys lives on the host side of the binding (nn.Module keeps its initial value for them). */
+int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n);
 
 /* Conditioning exactly as generate() builds it (fatchord_version.py:183-186:
  * pad_tensor 'both' + UpsampleNetwork.forward :82-89), materialised:

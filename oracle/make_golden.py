@@ -33,13 +33,21 @@ CASES = [
     dict(name='mol_default_b1_t24', mode='MOL', bits=9, variant='default', B=1, T=24, batched=False),
     dict(name='mol_default_b2_t21', mode='MOL', bits=9, variant='default', B=2, T=21, batched=False),
 ]
+# BASELINE-size cases (`python -m oracle.make_golden long`): configs[1] itself (B=1, T=401: 110 275 free-running
+# steps = 14 default segments of the shipped kernel) and a B=8 clip long enough for several natural segments
+# per row.  Only labels (+ the B=1 wav) are stored: the conditioning slices of the short cases already pin A2-A5.
+LONG_CASES = [
+    dict(name='raw_peaky_b1_t401', mode='RAW', bits=10, variant='peaky', B=1, T=401, batched=False, slim=True),
+    dict(name='raw_peaky_b8_t60', mode='RAW', bits=10, variant='peaky', B=8, T=60, batched=False, slim=True),
+]
 WEIGHT_SEED, MEL_SEED, NOISE_SEED = 0, 1234, 42
 
 
 def main() -> int:
     from oracle import ref_harness as rh
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    for c in CASES:
+    cases = LONG_CASES if (len(sys.argv) > 1 and sys.argv[1] == 'long') else CASES
+    for c in cases:
         sd = make_state_dict(WEIGHT_SEED, mode=c['mode'], variant=c['variant'], bits=c['bits'])
         model = rh.build_reference_model(sd, mode=c['mode'], bits=c['bits'])
         mels = make_mels(MEL_SEED, c['B'], c['T'])
@@ -58,6 +66,11 @@ def main() -> int:
             up_head=up[:, :320], up_tail=up[:, -320:], up_stride=up[:, ::41],
             aux_frames=aux[:, ::275],
         )
+        if c.get('slim'):
+            for k in ('up_head', 'up_tail', 'up_stride', 'aux_frames'):
+                del fix[k]
+            fix['wav'] = out['wav'].astype(np.float32) if c['B'] == 1 else np.zeros(0, np.float32)
+            fix['ref_seconds'] = out['seconds']
         if c['mode'] == 'RAW':
             fix['labels'] = out['labels'].astype(np.int16)
         else:

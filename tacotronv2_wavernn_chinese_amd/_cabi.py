@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libwavernn_amd.so')
 
 MODE_RAW, MODE_MOL = 0, 1
 NOISE_PHILOX, NOISE_INJECTED, NOISE_ARGMAX = 0, 1, 2
-KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM, KERNEL_TEAM2 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM2, KERNEL_BATCH = 0, 1, 3, 4
+KERNEL_NAMES = {KERNEL_AUTO: 'auto', KERNEL_SIMPLE: 'simple', KERNEL_TEAM2: 'team2', KERNEL_BATCH: 'batch'}
 DTYPE_F32, DTYPE_I64 = 0, 1
 ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN_ERR_STATE',
              -4: 'WRNN_ERR_MISSING_KEY', -5: 'WRNN_ERR_TIMEOUT'}
@@ -111,7 +112,7 @@ def load_library() -> C.CDLL:
     vp = C.c_void_p
     lib.wrnn_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.wrnn_create.restype = C.c_int
-    lib.wrnn_load_weights.argtypes = [vp, C.POINTER(TensorDesc), C.c_int32, C.c_int32]
+    lib.wrnn_load_weights.argtypes = [vp, C.POINTER(TensorDesc), C.c_int32]
     lib.wrnn_load_weights.restype = C.c_int
     lib.wrnn_conditioning.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
     lib.wrnn_conditioning.restype = C.c_int
@@ -200,8 +201,9 @@ class NativeVocoder:
         except Exception:
             pass
 
-    def load_weights(self, state_dict: Dict[str, np.ndarray], strict: bool = True):
-        """state_dict: name -> contiguous numpy array (float32 / int64), reference key names."""
+    def load_weights(self, state_dict: Dict[str, np.ndarray]):
+        """state_dict: name -> contiguous numpy array (float32 / int64), reference key names.  Every parameter the
+        path reads must be present with the reference's shape (WrnnError otherwise); other keys are ignored."""
         keep, descs = [], []
         for name, arr in state_dict.items():
             arr = np.ascontiguousarray(arr)
@@ -223,7 +225,7 @@ class NativeVocoder:
             keep.append(arr)
             descs.append(d)
         arr_t = (TensorDesc * len(descs))(*descs)
-        self._check(self.lib.wrnn_load_weights(self._h, arr_t, len(descs), 1 if strict else 0))
+        self._check(self.lib.wrnn_load_weights(self._h, arr_t, len(descs)))
         self.loop_weight_bytes = int(self.lib.wrnn_loop_weight_bytes(self._h))
 
     def plan(self, B: int, T: int, batched: bool, target: int, overlap: int) -> Tuple[int, int]:

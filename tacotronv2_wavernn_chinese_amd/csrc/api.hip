@@ -111,6 +111,24 @@ int wrnn_create(const wrnn_config *cfg, wrnn_handle **out) {
         h->n_teams = prop.multiProcessorCount / 32;
         if (h->n_teams > 8) h->n_teams = 8;
     }
+    {
+        // The team kernels spin on each other inside one launch: all n_teams * 32 workgroups must be resident at once,
+        // one per CU (they take most of a CU's LDS).  Establish that here, loudly, instead of discovering it as a
+        // bounded-spin timeout: the runtime must admit >= 1 workgroup per CU for every team kernel.
+        h->team_ok = true;
+        if (h->n_teams < 1) { h->team_ok = false; h->team_why = "fewer than 32 CUs visible (one team = the 32 CUs of an XCD)"; }
+        int blocks = 0;
+        size_t lds = 0;
+        if (h->team_ok) {
+            hipError_t e = wrnn_team2_occupancy(&blocks, &lds);
+            if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_team2_kernel cannot be resident (LDS/registers)"; }
+        }
+        for (int nq = 1; nq <= 2 && h->team_ok; ++nq) {
+            hipError_t e = wrnn_batch_occupancy(nq, &blocks, &lds);
+            if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_batch_kernel cannot be resident (LDS/registers)"; }
+        }
+        (void)hipGetLastError();
+    }
     for (int i = 0; i < 3; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
     HIP_TRY(h, hipMalloc(&h->err_dev, 64));
     HIP_TRY(h, hipMemset(h->err_dev, 0, 64));
@@ -126,6 +144,8 @@ void wrnn_destroy(wrnn_handle *h) {
     if (h->err_dev) (void)hipFree(h->err_dev);
     if (h->team_w) (void)hipFree(h->team_w);
     if (h->team_fc3) (void)hipFree(h->team_fc3);
+    if (h->batch_w) (void)hipFree(h->batch_w);
+    if (h->batch_fc3) (void)hipFree(h->batch_fc3);
     if (h->wI0) (void)hipFree(h->wI0);
     if (h->u1) (void)hipFree(h->u1);
     if (h->tab) (void)hipFree(h->tab);
@@ -143,9 +163,8 @@ const char *wrnn_last_error(const wrnn_handle *h) { return h ? h->err.c_str() : 
 int32_t wrnn_n_classes(const wrnn_handle *h) { return h ? h->d.NC : 0; }
 int64_t wrnn_loop_weight_bytes(const wrnn_handle *h) { return h ? h->loop_weight_bytes : 0; }
 
-int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n, int32_t strict) {
+int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n) {
     if (!h || !tensors) return WRNN_ERR_INVALID;
-    (void)strict;  // every parameter below is required by the path; extras are ignored (strict=False semantics)
     const WrnnDims &d = h->d;
     std::map<std::string, TensorView> tv;
     for (int i = 0; i < n; ++i)
@@ -155,9 +174,12 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
         if (it == tv.end()) return fail(h, WRNN_ERR_MISSING_KEY, "state_dict key missing: %s", name.c_str());
         const wrnn_tensor_desc *t = it->second.t;
         if (t->dtype != WRNN_DTYPE_F32) return fail(h, WRNN_ERR_INVALID, "%s: expected float32", name.c_str());
-        int64_t want = 1;
-        for (auto s : shape) want *= s;
-        if (it->second.numel() != want) return fail(h, WRNN_ERR_INVALID, "%s: expected %lld elements, got %lld", name.c_str(), (long long)want, (long long)it->second.numel());
+        if ((size_t)t->ndim != shape.size()) return fail(h, WRNN_ERR_INVALID, "%s: expected %d dimensions, got %d", name.c_str(), (int)shape.size(), (int)t->ndim);
+        int di = 0;
+        for (auto s : shape) {
+            if (t->shape[di] != s) return fail(h, WRNN_ERR_INVALID, "%s: dimension %d is %lld, expected %lld", name.c_str(), di, (long long)t->shape[di], (long long)s);
+            ++di;
+        }
         *out = it->second.f();
         return WRNN_OK;
     };
@@ -313,6 +335,37 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
             vu1[r] = (float)acc;
         }
     }
+    // ---- batch kernel layouts (loop_batch.hip): MFMA 4x4x1 A-operand images.  Lane (kp = lane>>2, i = lane&3) of wave
+    // wl of WG g holds W[row(16g + 4wl + i)][k], k = 64 S + 16 e + kp for register slab s = 4 S + e.
+    std::vector<float> bw((size_t)32 * 4 * 352 * 64, 0.0f), bf3((size_t)32 * 16384, 0.0f);
+    {
+        const float *whh1 = tv["rnn1.weight_hh_l0"].f(), *wih2 = tv["rnn2.weight_ih_l0"].f(), *whh2 = tv["rnn2.weight_hh_l0"].f();
+        const float *wfc1 = tv["fc1.weight"].f(), *wfc2 = tv["fc2.weight"].f(), *wfc3 = tv["fc3.weight"].f();
+        for (int g = 0; g < 32; ++g)
+            for (int wl = 0; wl < 4; ++wl)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int kp = lane >> 2, i = lane & 3;
+                    const int u = 16 * g + 4 * wl + i;
+                    // register r of the wave: W_ih2 r,z,n [0,96) | W_hh1 [96,192) | W_hh2 [192,288) | fc1 [288,320) | fc2 [320,352)
+                    auto at = [&](int r) -> float & { return bw[(((size_t)g * 4 + wl) * 352 + r) * 64 + lane]; };
+                    for (int s2 = 0; s2 < 32; ++s2) {
+                        const int k = 64 * (s2 >> 2) + 16 * (s2 & 3) + kp;
+                        for (int gate = 0; gate < 3; ++gate) {
+                            const size_t row = (size_t)gate * H + u;
+                            at(gate * 32 + s2) = wih2[row * (H + A) + k];
+                            at(96 + gate * 32 + s2) = whh1[row * H + k];
+                            at(192 + gate * 32 + s2) = whh2[row * H + k];
+                        }
+                        at(288 + s2) = wfc1[(size_t)u * (H + A) + k];
+                        at(320 + s2) = wfc2[(size_t)u * (FC + A) + k];
+                        for (int set = 0; set < 2; ++set) {
+                            const int row = 32 * g + 8 * wl + 4 * set + i;
+                            if (row < NC)
+                                bf3[(size_t)g * 16384 + ((size_t)((wl * 2 + set) * 8 + (s2 >> 2)) * 64 + lane) * 4 + (s2 & 3)] = wfc3[(size_t)row * FC + k];
+                        }
+                    }
+                }
+    }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     auto upload = [&](float *&dst, const std::vector<float> &src) -> int {
         if (dst) { (void)hipFree(dst); dst = nullptr; }
@@ -320,9 +373,10 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
         HIP_TRY(h, hipMemcpy(dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
         return WRNN_OK;
     };
-    if ((rc = upload(h->team_w, tw)) || (rc = upload(h->team_fc3, tf3)) || (rc = upload(h->wI0, vwI0)) || (rc = upload(h->u1, vu1))) return rc;
+    if ((rc = upload(h->team_w, tw)) || (rc = upload(h->team_fc3, tf3)) || (rc = upload(h->wI0, vwI0)) || (rc = upload(h->u1, vu1)) ||
+        (rc = upload(h->batch_w, bw)) || (rc = upload(h->batch_fc3, bf3))) return rc;
     if (!h->mail) {
-        HIP_TRY(h, hipMalloc(&h->mail, (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMalloc(&h->mail, (size_t)8 * WRNN_MAIL_GRANULES_MAX * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->ctl, 128));
         if (getenv("WRNN_TEAM_PROF")) { HIP_TRY(h, hipMalloc(&h->prof, 8 * 17 * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->prof, 0, 8 * 17 * sizeof(unsigned long long))); }
     }
@@ -395,21 +449,14 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
 
-    // rows table
-    std::vector<WrnnRow> rowsh(rows);
-    for (int r = 0; r < rows; ++r) {
-        rowsh[r].utt = batched ? 0 : r;
-        rowsh[r].pad_ = 0;
-        rowsh[r].start = batched ? (int64_t)r * ((int64_t)target + overlap) : 0;
-    }
+    // rows table, built on the device: nothing is staged on the host, the call never waits for the stream
     if ((size_t)rows > h->rows_cap) {
         if (h->rows_dev) (void)hipFree(h->rows_dev);
         h->rows_dev = nullptr; h->rows_cap = 0;
         HIP_TRY(h, hipMalloc(&h->rows_dev, (size_t)rows * sizeof(WrnnRow)));
         h->rows_cap = rows;
     }
-    HIP_TRY(h, hipMemcpyAsync(h->rows_dev, rowsh.data(), (size_t)rows * sizeof(WrnnRow), hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipStreamSynchronize(s));  // rowsh is a stack-lifetime staging buffer
+    HIP_TRY(h, wrnn_launch_rows(h->rows_dev, rows, batched, (long)target + overlap, s));
     if (int rc = ensure_aux(h, B, T)) return rc;
     HIP_TRY(h, hipMemsetAsync(h->err_dev, 0, 64, s));
 
@@ -425,20 +472,26 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     a.samples_out = samples_out_dev; a.err = h->err_dev;
     int kernel = opts->kernel;
     int launches = 1;
+    // what the team kernels (TEAM2, BATCH) need: co-residency (checked in wrnn_create), the 5-frame upsampling support
+    // of pad = 2, hop <= 275, and 1024 or fewer classes.  AUTO falls back to the any-shape kernel otherwise;
+    // an explicit request for a team kernel that cannot run is an error.
+    const char *team_no = nullptr;
+    if (!h->team_ok) team_no = h->team_why.c_str();
+    else if (d.ND != 5 || d.HOP > 275) team_no = "team kernels are built for pad=2 (5-frame upsampling support), hop <= 275";
     if (kernel == WRNN_KERNEL_AUTO) {
-        kernel = WRNN_KERNEL_TEAM2;
+        if (team_no) kernel = WRNN_KERNEL_SIMPLE;
+        else kernel = rows <= h->n_teams ? WRNN_KERNEL_TEAM2 : WRNN_KERNEL_BATCH;   // one row per XCD team: the latency kernel
     }
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));
-    } else if (kernel == WRNN_KERNEL_TEAM || kernel == WRNN_KERNEL_TEAM2) {
-        if (h->n_teams < 1) return fail(h, WRNN_ERR_INVALID, "team kernels need at least one full XCD (32 CUs)");
-        if (d.ND != 5 || d.HOP > 275) return fail(h, WRNN_ERR_INVALID, "team kernel is built for pad=2 (5-frame upsampling support), hop <= 275");
+    } else if (kernel == WRNN_KERNEL_TEAM2 || kernel == WRNN_KERNEL_BATCH) {
+        if (team_no) return fail(h, WRNN_ERR_INVALID, "%s", team_no);
         // conditioning pushed through the linear layers it feeds (once per call)
         const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, P = d.P;
         const int TP = T + 2 * P, T1 = T + 1;
         const size_t nCM = (size_t)B * TP * H, nCA = (size_t)B * T1 * H, nVM = (size_t)B * TP * 3 * H, nVA = (size_t)B * T1 * 3 * H;
         const size_t nC2 = (size_t)B * T1 * 3 * H, nC3 = (size_t)B * T1 * FC, nC4 = (size_t)B * T1 * FC;
-        const size_t nREC = (size_t)B * T1 * H * 28;
+        const size_t nREC = (size_t)B * T1 * H * (kernel == WRNN_KERNEL_BATCH ? 32 : 28);
         const size_t need = nCM + nCA + nVM + nVA + nC2 + nC3 + nC4 + nREC;
         if (need > h->tab_cap) {
             if (h->tab) (void)hipFree(h->tab);
@@ -456,6 +509,28 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + A, (size_t)T * R, R, T, w + o.r2_wih_t + (size_t)H * 3 * H, 3 * H, w + o.r2_bih, tC2, (size_t)T1 * 3 * H, T1, A, 3 * H, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 2 * A, (size_t)T * R, R, T, w + o.fc1_t + (size_t)H * FC, FC, w + o.fc1_b, tC3, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 3 * A, (size_t)T * R, R, T, w + o.fc2_t + (size_t)FC * FC, FC, w + o.fc2_b, tC4, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
+        const size_t mail_bytes = (size_t)8 * WRNN_MAIL_GRANULES_MAX * sizeof(unsigned long long);
+        if (kernel == WRNN_KERNEL_BATCH) {
+            // R = 4 * nq rows per XCD team in lock-step on the matrix cores (loop_batch.hip); the rows are spread evenly over
+            // the teams first (rpb rows per batch), a team runs ceil(batches / n_teams) batches one after the other
+            HIP_TRY(h, wrnn_launch_pack_records32(tCM, tCA, tVM, tVA, tC2, tC3, tC4, tREC, B, T, P, s));
+            int rpb = (rows + h->n_teams - 1) / h->n_teams;
+            if (rpb > WRNN_BATCH_MAX_ROWS) rpb = WRNN_BATCH_MAX_ROWS;
+            if (const char *e = getenv("WRNN_BATCH_ROWS")) { rpb = atoi(e); if (rpb < 1) rpb = 1; if (rpb > WRNN_BATCH_MAX_ROWS) rpb = WRNN_BATCH_MAX_ROWS; }   // developer knob
+            WrnnBatchArgs ba{};
+            ba.w = w; ba.off = o; ba.d = d; ba.batch_w = h->batch_w; ba.batch_fc3 = h->batch_fc3; ba.wI0 = h->wI0; ba.u1 = h->u1;
+            ba.tabREC32 = tREC; ba.rows = h->rows_dev; ba.n_rows = rows; ba.n_teams = h->n_teams; ba.nq = rpb <= 4 ? 1 : 2; ba.rpb = rpb;
+            ba.T = T; ba.total_len = a.total_len; ba.steps = steps;
+            ba.noise_mode = a.noise_mode; ba.seed = a.seed; ba.noise1 = a.noise1; ba.noise2 = a.noise2; ba.x_forced = a.x_forced;
+            ba.logits_out = a.logits_out; ba.labels_out = a.labels_out; ba.samples_out = a.samples_out;
+            ba.mail = h->mail; ba.ctl = h->ctl; ba.err = h->err_dev; ba.prof = h->prof;
+            HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
+            HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
+            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * 17 * sizeof(unsigned long long), s));
+            HIP_TRY(h, hipEventRecord(h->ev[1], s));  // tables and records are prologue work
+            HIP_TRY(h, wrnn_launch_loop_batch(ba, s));
+            h->prof_div = (double)steps * ((((rows + rpb - 1) / rpb) + h->n_teams - 1) / h->n_teams);
+        } else {
         HIP_TRY(h, wrnn_launch_pack_records(tCM, tCA, tVM, tVA, tREC, B, T, P, s));
         WrnnTeamArgs ta{};
         ta.w = w; ta.off = o; ta.d = d; ta.team_w = h->team_w; ta.team_fc3 = h->team_fc3; ta.wI0 = h->wI0; ta.u1 = h->u1;
@@ -465,8 +540,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced;
         ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
         ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;
-        const size_t mail_bytes = (size_t)8 * WRNN_TEAM_MAIL_GRANULES * sizeof(unsigned long long);
-        if (kernel == WRNN_KERNEL_TEAM2) {
+        {
             // The phase-A conditioning is streamed from HBM (8 KB per row and step).  A row is generated in segments,
             // one stream chunk + one loop launch each, sized so that the chunk (~64 MB over all rows) is still resident
             // in the memory-side cache when the loop reads it: against a stream written once for the whole clip
@@ -495,6 +569,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work; the stream chunks are timed with the loop
             if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * 17 * sizeof(unsigned long long), s));
             ta.team_w = h->team_w; ta.tabCOND = h->cond; ta.state = h->team_state;
+            h->prof_div = (double)steps * ((rows + h->n_teams - 1) / h->n_teams);
             for (int64_t t0 = 0; t0 < steps; t0 += seg) {
                 const int64_t len = steps - t0 < seg ? steps - t0 : seg;
                 HIP_TRY(h, wrnn_launch_cond_stream(tREC, w + o.ktab, h->rows_dev, h->cond, rows, T, d.HOP, a.total_len, t0, len, s));
@@ -504,12 +579,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
                 HIP_TRY(h, wrnn_launch_loop_team2(ta, s));
                 launches = (int)(t0 / seg) + 1;
             }
-        } else {
-            HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
-            HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
-            HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work
-            ta.prof = nullptr;   // phase-cycle instrumentation exists for the shipped kernel (TEAM2) only
-            HIP_TRY(h, wrnn_launch_loop_team(ta, s));
+        }
         }
     } else {
         return fail(h, WRNN_ERR_INVALID, "kernel %d not available", kernel);
@@ -530,12 +600,12 @@ int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out) {
     unsigned errw = 0;
     HIP_TRY(h, hipMemcpy(&errw, h->err_dev, sizeof(errw), hipMemcpyDeviceToHost));
     if (out) *out = h->last;
-    if (h->prof && h->last.kernel == WRNN_KERNEL_TEAM2) {
+    if (h->prof && (h->last.kernel == WRNN_KERNEL_TEAM2 || h->last.kernel == WRNN_KERNEL_BATCH)) {
         unsigned long long pr[8 * 17];
         HIP_TRY(h, hipMemcpy(pr, h->prof, sizeof(pr), hipMemcpyDeviceToHost));
-        const double n = (double)h->last.steps * ((h->last.rows + 7) / 8);
+        const double n = h->prof_div > 0 ? h->prof_div : 1.0;   // steps x rows (or batches) team 0 ran
         for (int wv = 0; wv < 8; ++wv) {
-            fprintf(stderr, "[wrnn prof] %s %d cycles/step:", h->last.kernel == WRNN_KERNEL_TEAM2 ? "team2 wg0 wave" : (wv < 4 ? "team wg0 wave" : "team wg31 wave"), h->last.kernel == WRNN_KERNEL_TEAM2 ? wv : (wv & 3));
+            fprintf(stderr, "[wrnn prof] %s %d cycles/step:", h->last.kernel == WRNN_KERNEL_TEAM2 ? "team2 wg0 wave" : "batch wg0 wave", wv);
             double tot = 0;
             for (int i = 0; i < 17; ++i) { fprintf(stderr, " %.0f", pr[wv * 17 + i] / n); tot += pr[wv * 17 + i] / n; }
             fprintf(stderr, " | total %.0f\n", tot);

@@ -1,0 +1,698 @@
+// WRNN_KERNEL_BATCH: the per-sample loop (fatchord_version.py:194-241) for MANY rows per team, in lock-step, on the
+// matrix cores.  The reference advances all B rows of a batch together (h1/h2 are (B, 512), :194-196; every layer is one
+// batched matmul, :209-223); this kernel does the same per XCD team: R = 4*NQ rows step together, so every weight that
+// sits in a register is used R times per step instead of once (loop_team2.hip), and one exchange / barrier / reduction
+// tree serves R rows.
+//
+// Team, residency and exchange protocol are those of loop_team2.hip: one team = the 32 workgroups of one XCD (formed from
+// HW_REG_XCC_ID at run time), fp32 weights resident in registers / LDS, 8-byte {tag, value} granules through the XCD's L2
+// (plain store, sc1 load, the data is the flag), parity double-buffering, bounded spins.  What is different:
+//
+//  * Arithmetic on v_mfma_f32_4x4x1_16b_f32 (exact fp32, the vector FMA rate from ONE instruction per 256 MACs).  The
+//    instruction is 16 independent 4x4 outer products: block b = lane>>2 multiplies A_b[i = lane&3] by B_b[j = lane&3]
+//    and accumulates D_b[i][j] (vgpr i of lane (b, j)).  Here a block is one K phase kp = lane>>2, i = one of the 4
+//    weight rows (hidden units / fc rows) the wave owns, j = one of 4 rows of the batch:
+//        A lane (kp, i) = W[unit_i][k],   B lane (kp, j) = x[k][row_j],   k = 64 S + 16 e + kp   (slab s = 4 S + e)
+//    so one A register holds 64 DISTINCT weights (no replication: the register file is ~70 % weights) and serves 4 batch
+//    rows per issue; R = 8 rows = two issues with the same A.  The K sum runs through the accumulator (32 slabs), the
+//    16 K phases are folded once per phase with 2 v_permlane32_swap + 1 v_permlane16_swap + 2 DPP adds -- instead
+//    of a 4-step DPP reduction per row and output.  The B operand is one conflict-free ds_read_b128 per 4 issues.
+//  * 4 waves per workgroup, one per SIMD, 512 registers each (VGPR + AGPR; MFMA reads A operands from either): a wave
+//    holds ALL weight rows of its 4 hidden units -- W_hh1, W_ih2, W_hh2 (3 gates each), fc1, fc2: 352 registers -- and its
+//    8 fc3 rows sit in LDS.  (Two waves per SIMD at 256 registers each, the team2 split, spills ~100-220 registers to
+//    scratch here: measured with -Rpass-analysis.)  What team2 gave to "shadow" waves runs in the same instruction stream,
+//    right after the publish of each phase and before the poll of its exchange: W_hh1.h1' (window 2), W_hh2.h2' (window 3),
+//    sampling noise and the next step's conditioning (window 4).  MFMA issue is asynchronous to the wave's VALU / LDS
+//    stream, and nothing needs a hand-off through LDS: gh1, gh2, conditioning, noise stay in the owning thread's registers.
+//  * Phase A (I + GRU1, elementwise) is no longer replicated in every workgroup: each workgroup evaluates its own 16 hidden
+//    units for the R rows and publishes x2 and h1' (one more exchange than team2, but no 8 KB/step/row conditioning stream:
+//    a workgroup needs the conditioning of 16 units only, evaluated from the per-frame records with the 5-tap form; HBM
+//    traffic per sample ~ the 836 B of SURVEY 8d instead of 8 KB).
+//  * Thread (wl, lane) is "unit 16 g + 4 wl + U(lane>>4), batch row 4 (kp2 % NQ) + (lane & 3)", kp2 = (lane>>2)&3,
+//    U = {0, 2, 1, 3} (where the fold leaves the units); lanes with kp2 >= NQ hold duplicates and publish nothing.
+//
+// Per step: 5 exchanges (x2|h1', x3, fc1, fc2, race winners), 5 workgroup barriers.  Every exchange is an all-gather of
+// R x 512 granules in the order the B operand wants them in LDS, read with 16-byte sc1 loads (two granules each).
+#include "device_util.h"
+#include "wrnn_internal.h"
+
+#define TB_WGS 32
+#define TB_THREADS 256
+#define TB_SPIN_MAX 400000u
+
+typedef unsigned long long u64;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ unsigned xcc_idb() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+__device__ __forceinline__ void st_granule(u64 *base, unsigned idx, unsigned tag, unsigned payload) {
+    const u64 v = ((u64)tag << 32) | payload;
+    const unsigned off = idx * 8u;
+    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+// 16-byte sc1 load (L1 bypass) of two adjacent granules; compiler-tracked (s_waitcnt vmcnt inserted by hipcc)
+__device__ __forceinline__ u4v ld_pair(__amdgpu_buffer_rsrc_t rs, unsigned byteoff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, byteoff, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// fold the 16 K phases: in d[i] lane (kp, j) = partial of unit i, batch row j; out: lane (rho = lane>>4, *, j) = full sum
+// of unit {0, 2, 1, 3}[rho] for batch row j, replicated over the 4 lanes-of-four of the row
+__device__ __forceinline__ float fold_kp(f4 d) {
+    const u2v p = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0]), __float_as_uint(d[1]), false, false);
+    const float s01 = __uint_as_float(p.x) + __uint_as_float(p.y);
+    const u2v q = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[2]), __float_as_uint(d[3]), false, false);
+    const float s23 = __uint_as_float(q.x) + __uint_as_float(q.y);
+    const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+    float t = __uint_as_float(r.x) + __uint_as_float(r.y);
+    t += dppf<0x124>(t);   // row_ror:4
+    t += dppf<0x128>(t);   // row_ror:8
+    return t;
+}
+__device__ __forceinline__ float wave_max_b(float v) {   // max over 64 lanes, valid in lane 63 (see loop_team2.hip)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+
+// ---- LDS carve-up (floats) -----------------------------------------------------------------------------------------
+template <int NQ>
+struct Lay {
+    static constexpr int R = 4 * NQ;
+    static constexpr int VEC = R * 512;            // one activation vector for R rows, B-operand order [rq][S][kp][j][e]
+    static constexpr int L_FC3 = 0;                // [4 waves][2 sets][8 S][64 lanes][4 e]: A operands of the fc3 slice
+    static constexpr int L_P = 16384;              // x2, later fc1 outputs
+    static constexpr int L_Q = L_P + VEC;          // x3, later fc2 outputs
+    static constexpr int L_H2 = L_Q + VEC;         // h2' = x3 - x2
+    static constexpr int L_H1 = L_H2 + VEC;        // h1'
+    static constexpr int L_XN = L_H1 + VEC;        // [16] x_{t-1} of every batch row
+    static constexpr int L_MISC = L_XN + 16;       // [16]
+    static constexpr int L_TOTAL = L_MISC + 16;
+    static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
+    // mailbox regions per team (granules); every region is double-buffered by step parity
+    static constexpr unsigned RG = (unsigned)VEC;
+    static constexpr unsigned G_X2 = 0, G_H1 = 2 * RG, G_X3 = 4 * RG, G_F1 = 6 * RG, G_F2 = 8 * RG, G_PR = 10 * RG;
+    static constexpr unsigned PRG = (unsigned)R * 128u;
+    static constexpr unsigned MAIL = 10 * RG + 2 * PRG;
+    static_assert(MAIL <= WRNN_BATCH_MAIL_GRANULES, "mailbox budget");
+    static constexpr int NM = R;                   // 16-byte loads per thread per gathered vector (256 threads)
+};
+constexpr int M_DEAD = 0, M_TEAM = 1, M_RANK = 2;
+
+// gather one published vector (R x 512 granules, mailbox order [rq][wl][S][iu][j][e]) : slice m = (rq, wl) holds the
+// granules wave wl of EVERY workgroup published for row quad rq.  The last slice is polled first (the wave that is
+// dispatched last tends to publish last); the rest is fetched once it is complete.
+template <int NM>
+__device__ __forceinline__ void gather_vec(__amdgpu_buffer_rsrc_t rs, unsigned byteoff, unsigned tag, u4v (&g)[NM], bool &dead,
+                                           unsigned *err, unsigned code) {
+    unsigned spins = 0;
+    g[NM - 1] = ld_pair(rs, byteoff + (NM - 1) * 4096u);
+    while (!dead && !__all(g[NM - 1].y == tag && g[NM - 1].w == tag)) {
+        if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+        __builtin_amdgcn_s_sleep(1);
+        g[NM - 1] = ld_pair(rs, byteoff + (NM - 1) * 4096u);
+    }
+#pragma unroll
+    for (int m = 0; m < NM - 1; ++m) g[m] = ld_pair(rs, byteoff + m * 4096u);
+    bool ok = true;
+#pragma unroll
+    for (int m = 0; m < NM - 1; ++m) ok = ok && g[m].y == tag && g[m].w == tag;
+    while (!dead && !__all(ok)) {
+        if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code + 100u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        ok = true;
+#pragma unroll
+        for (int m = 0; m < NM - 1; ++m) { g[m] = ld_pair(rs, byteoff + m * 4096u); ok = ok && g[m].y == tag && g[m].w == tag; }
+    }
+}
+
+// acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane]
+template <int NQ, int NG>
+__device__ __forceinline__ void mfma_gates(const float *w, const f4 *xv, int lane, f4 (&acc)[NG][NQ]) {
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+        f4 b[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int gt = 0; gt < NG; ++gt)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[gt][q] = mfma4(w[gt * 32 + 4 * S + e], b[q][e], acc[gt][q]);
+    }
+}
+// one weight row set (32 slabs at w[..]); the K sum is split over NP independent accumulator chains
+template <int NQ, int NP>
+__device__ __forceinline__ void mfma_single(const float *w, const f4 *xv, int lane, f4 (&sum)[NQ]) {
+    f4 acc[NP][NQ];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[p][q] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+        f4 b[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[e % NP][q] = mfma4(w[4 * S + e], b[q][e], acc[e % NP][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        sum[q] = acc[0][q];
+#pragma unroll
+        for (int p = 1; p < NP; ++p) sum[q] += acc[p][q];
+    }
+}
+
+}  // namespace
+
+#define PB(i)                                                    \
+    do {                                                         \
+        if (PROF) {                                              \
+            const u64 now_ = __builtin_readcyclecounter();       \
+            prof_acc[i] += now_ - prof_last;                     \
+            prof_last = now_;                                    \
+        }                                                        \
+    } while (0)
+
+template <int MODE, int NQ, bool PROF>
+__global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a) {
+    typedef Lay<NQ> L;
+    constexpr int R = L::R, NM = L::NM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = (float *)smem;
+    int *misc_i = (int *)(lds + L::L_MISC);
+    float *xn = lds + L::L_XN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 3, kp2 = (lane >> 2) & 3, rho = lane >> 4;
+    const int iu = ((rho & 1) << 1) | (rho >> 1);          // unit the fold leaves in this row of 16 lanes: {0, 2, 1, 3}
+    const int my_rq = kp2 % NQ;
+    const bool primary = kp2 < NQ;                         // the other lanes of four hold duplicates
+    const int rb = 4 * my_rq + j;                          // batch row (0..R-1) of this thread
+    const WrnnDims d = a.d;
+    const int NC = d.NC, HOP = d.HOP, T = a.T;
+
+    // ---- team formation: by the XCD this workgroup actually runs on (see loop_team2.hip) ------------
+    if (tid == 0) {
+        const unsigned x = xcc_idb();
+        misc_i[M_DEAD] = 0;
+        const unsigned rank = atomicAdd(&a.ctl[x], 1u);
+        unsigned slot1 = 0;
+        if (rank == 0) {
+            slot1 = atomicAdd(&a.ctl[8], 1u) + 1u;
+            __hip_atomic_store(&a.ctl[16 + x], slot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (unsigned spins = 0; spins < 4000000u; ++spins) {
+                slot1 = __hip_atomic_load(&a.ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot1) break;
+            }
+        }
+        misc_i[M_TEAM] = slot1 ? (int)slot1 - 1 : 1 << 20;
+        misc_i[M_RANK] = (int)rank;
+    }
+    __syncthreads();
+    const int team = __builtin_amdgcn_readfirstlane(misc_i[M_TEAM]);
+    const int g = __builtin_amdgcn_readfirstlane(misc_i[M_RANK]);
+    __syncthreads();
+    const int n_batches = (a.n_rows + a.rpb - 1) / a.rpb;
+    if (g >= TB_WGS || team >= a.n_teams || team >= n_batches) return;
+    u64 *mail = a.mail + (size_t)team * WRNN_BATCH_MAIL_GRANULES;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)mail, 0, (int)(WRNN_BATCH_MAIL_GRANULES * 8u), 0x00020000);
+
+    const int unit = 16 * g + 4 * wl + iu;                 // hidden unit / fc1 / fc2 row of this thread (fold layout)
+    const int cls0 = 32 * g + 8 * wl + iu;                 // fc3 rows (classes) of this thread: cls0 and cls0 + 4
+    const bool wg_has_fc3 = 32 * g < NC;
+    // mailbox index of this thread's (unit, batch row) in a gathered vector: [rq][wl][S = g>>2][iu][j][e = g&3]
+    const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
+    // where gathered pair m = (rq, wl') of this thread goes in LDS (floats): tid = S*32 + iu*8 + j*2 + e/2
+    //   -> [rq][S = tid>>5][kp = 4 wl' + iu][j][e] = ((rq*8 + S)*16 + 4 wl')*16 + 2*(tid & 31)
+    auto pair_dst = [&](int m) { return (((m >> 2) * 8 + (tid >> 5)) * 16 + 4 * (m & 3)) * 16 + 2 * (tid & 31); };
+
+    // ---- resident weights: batch_w [32 WG][4 waves][352][64 lanes] (A-operand images, api.hip):
+    //      W_ih2 r,z,n [0,96) | W_hh1 r,z,n [96,192) | W_hh2 r,z,n [192,288) | fc1 [288,320) | fc2 [320,352)
+    float wv[352];
+    {
+        const float *src = a.batch_w + (((size_t)g * 4 + wl) * 352) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 352; ++i) wv[i] = src[(size_t)i * 64];
+        const float4 *f3 = (const float4 *)(a.batch_fc3 + (size_t)g * 16384);
+        float4 *dst = (float4 *)(lds + L::L_FC3);
+        for (int i = tid; i < 4096; i += TB_THREADS) dst[i] = f3[i];
+        for (int i = tid; i < L::L_TOTAL - L::L_P; i += TB_THREADS) lds[L::L_P + i] = 0.0f;
+    }
+    // per-thread constants: W_I[:,0] and u = W_ih1.W_I[:,0] of `unit`, recurrent biases, fc3 biases
+    const float cA0 = a.wI0[unit], cA1 = a.u1[unit], cA2 = a.u1[512 + unit], cA3 = a.u1[1024 + unit];
+    const float b30 = cls0 < NC ? a.w[a.off.fc3_b + cls0] : 0.0f, b31 = cls0 + 4 < NC ? a.w[a.off.fc3_b + cls0 + 4] : 0.0f;
+    const float bh1r = a.w[a.off.r1_bhh + unit], bh1z = a.w[a.off.r1_bhh + 512 + unit], bh1n = a.w[a.off.r1_bhh + 1024 + unit];
+    const float bh2r = a.w[a.off.r2_bhh + unit], bh2z = a.w[a.off.r2_bhh + 512 + unit], bh2n = a.w[a.off.r2_bhh + 1024 + unit];
+    __syncthreads();
+
+    const f4 *vP = (const f4 *)(lds + L::L_P), *vQ = (const f4 *)(lds + L::L_Q);
+    const f4 *vH1 = (const f4 *)(lds + L::L_H1), *vH2 = (const f4 *)(lds + L::L_H2);
+
+    bool dead = false;
+    unsigned epoch = 0;
+    u64 prof_acc[16] = {0};
+    u64 prof_last = 0;
+
+    for (int batch = team; batch < n_batches; batch += a.n_teams) {
+        const int row_raw = batch * a.rpb + rb;
+        const bool row_ok = rb < a.rpb && row_raw < a.n_rows;
+        const int row = row_ok ? row_raw : a.n_rows - 1;     // spare slots of a batch re-run the last row (outputs masked)
+        const WrnnRow rw = a.rows[row];
+        const float *recb = a.tabREC32 + (size_t)rw.utt * (T + 1) * 512 * 32 + (size_t)unit * 32;
+        const float *ktab = a.w + a.off.ktab;
+
+        // h1 = h2 = 0, x = 0 (:194-196)  =>  gh1 = b_hh1, gh2 = b_hh2
+        float h1 = 0.0f, h2 = 0.0f, x2own = 0.0f;
+        float gh1r = bh1r, gh1z = bh1z, gh1n = bh1n, gh2r = bh2r, gh2z = bh2z, gh2n = bh2n;
+        float4 cd = make_float4(0.f, 0.f, 0.f, 0.f);      // {cI, v_r, v_z, v_n} of the coming step
+        float4 c2 = make_float4(0.f, 0.f, 0.f, 0.f);      // {c2_r, c2_z, c2_n, c3} of the current frame
+        float c4 = 0.0f;
+        float nz0 = 0.f, nz1 = 0.f, pz0 = 0.f, pz1 = 0.f;  // -log q of classes cls0 / cls0+4: this step | the odd step of the Philox block
+        int nfi = (int)(rw.start / HOP), nph = (int)(rw.start - (int64_t)nfi * HOP);   // frame / phase of the step being prepared
+        int cst_frame = -1000000, pend_frame = -1;
+        if (tid < R) xn[tid] = 0.0f;
+
+        // conditioning {cI, v_r, v_z, v_n} of step ts for (unit, row): record + 5-tap upsampling (prologue.hip)
+        auto prep_cond = [&](int64_t ts) {
+            const int64_t pos = rw.start + ts;
+            const bool live = pos < a.total_len;           // fold padding 'after' = zero rows (:327-330)
+            const int fi = live ? nfi : T;                 // T = the all-zero conditioning record
+            const int ph = live ? nph : 0;
+            if (++nph == HOP) { nph = 0; ++nfi; }
+            pend_frame = fi;
+            const float4 *r = (const float4 *)(recb + (size_t)fi * 512 * 32);
+            const float4 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4], a5 = r[5];
+            const float *kt = ktab + ph * 5;
+            const float k0 = kt[0], k1 = kt[1], k2 = kt[2], k3 = kt[3], k4 = kt[4];
+            cd.x = fmaf(k4, a2.x, fmaf(k3, a1.w, fmaf(k2, a1.z, fmaf(k1, a1.y, fmaf(k0, a1.x, a0.x)))));
+            cd.y = fmaf(k4, a5.y, fmaf(k3, a4.z, fmaf(k2, a3.w, fmaf(k1, a3.x, fmaf(k0, a2.y, a0.y)))));
+            cd.z = fmaf(k4, a5.z, fmaf(k3, a4.w, fmaf(k2, a4.x, fmaf(k1, a3.y, fmaf(k0, a2.z, a0.z)))));
+            cd.w = fmaf(k4, a5.w, fmaf(k3, a5.x, fmaf(k2, a4.y, fmaf(k1, a3.z, fmaf(k0, a2.w, a0.w)))));
+        };
+        // per-frame constants of (unit, row) once the frame changed: c2 (r,z,n), c3, c4 (record slots 24..28)
+        auto frame_consts = [&]() {
+            if (pend_frame != cst_frame) {
+                const float4 *r = (const float4 *)(recb + (size_t)pend_frame * 512 * 32);
+                c2 = r[6];
+                c4 = recb[(size_t)pend_frame * 512 * 32 + 28];
+                cst_frame = pend_frame;
+            }
+        };
+        // -log q of this thread's two classes for step ts (RAW)
+        auto prep_noise = [&](int64_t ts) {
+            if (MODE != WRNN_MODE_RAW) return;
+            if (a.noise_mode == WRNN_NOISE_INJECTED) {
+                const float *qp = a.noise1 + ((size_t)ts * a.n_rows + row) * NC;
+                nz0 = cls0 < NC ? -logf(qp[cls0]) : 0.0f;
+                nz1 = cls0 + 4 < NC ? -logf(qp[cls0 + 4]) : 0.0f;
+            } else if (a.noise_mode == WRNN_NOISE_PHILOX) {
+                // one Philox block = classes (2c, 2c+1) x steps (2s, 2s+1) (device_util.h): evaluated on even steps, the odd
+                // step's draws are kept
+                if ((ts & 1) == 0) {
+                    const Philox4 p0 = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)cls0);
+                    const Philox4 p1 = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)(cls0 + 4));
+                    const bool oddc = (cls0 & 1) != 0;
+                    nz0 = -__logf(-__logf(u01_from_bits(oddc ? p0.y : p0.x)));
+                    nz1 = -__logf(-__logf(u01_from_bits(oddc ? p1.y : p1.x)));
+                    pz0 = -__logf(-__logf(u01_from_bits(oddc ? p0.w : p0.z)));
+                    pz1 = -__logf(-__logf(u01_from_bits(oddc ? p1.w : p1.z)));
+                } else { nz0 = pz0; nz1 = pz1; }
+            } else { nz0 = 0.f; nz1 = 0.f; }
+        };
+        prep_cond(0);
+        __syncthreads();
+
+        for (int64_t t = 0; t < a.steps; ++t) {
+            ++epoch;
+            const unsigned par = epoch & 1u;
+            if (PROF) prof_last = __builtin_readcyclecounter();
+
+            // ================= window 1: phase A | publish x2, h1' | gather both =================
+            {
+                // I + GRU1 for (unit, row) (:208-212); gi = u * x_{t-1} + v[t] (algebra: DESIGN.md 3.2)
+                const float xprev = xn[rb];
+                const float xin = fmaf(cA0, xprev, cd.x);
+                const float rg = sigmoid_fast(fmaf(cA1, xprev, cd.y) + gh1r);
+                const float zg = sigmoid_fast(fmaf(cA2, xprev, cd.z) + gh1z);
+                const float ng = tanh_fast(fmaf(cA3, xprev, cd.w) + rg * gh1n);
+                h1 = (1.0f - zg) * ng + zg * h1;
+                x2own = xin + h1;
+                if (primary) {
+                    st_granule(mail, L::G_X2 + par * L::RG + mb_own, epoch, __float_as_uint(x2own));
+                    st_granule(mail, L::G_H1 + par * L::RG + mb_own, epoch, __float_as_uint(h1));
+                }
+                frame_consts();   // constants of this step's frame (needed from phase B on)
+            }
+            PB(0);
+            {
+                u4v gx[NM];
+                gather_vec<NM>(mrs, (L::G_X2 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 21u);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
+                gather_vec<NM>(mrs, (L::G_H1 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 22u);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
+            }
+            PB(1);
+            __syncthreads();   // B1
+            PB(2);
+
+            // ================= window 2: phase B (GRU2, :213-216) | gh1' = W_hh1 . h1' | gather x3 =================
+            {
+                f4 acc[3][NQ];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
+                mfma_gates<NQ, 3>(wv, vP, lane, acc);
+                float tr = 0.f, tz = 0.f, tn = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
+                    if (q == 0 || my_rq == q) { tr = fr; tz = fz; tn = fn; }
+                }
+                const float rg = sigmoid_fast((tr + c2.x) + gh2r);
+                const float zg = sigmoid_fast((tz + c2.y) + gh2z);
+                const float ng = tanh_fast((tn + c2.z) + rg * gh2n);
+                h2 = (1.0f - zg) * ng + zg * h2;
+                const float x3 = x2own + h2;
+                if (primary) st_granule(mail, L::G_X3 + par * L::RG + mb_own, epoch, __float_as_uint(x3));
+            }
+            PB(3);
+            {
+                // off the serial chain, under the x3 exchange: gh1 of the next step
+                f4 acc[3][NQ];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
+                mfma_gates<NQ, 3>(wv + 96, vH1, lane, acc);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
+                    if (q == 0 || my_rq == q) { gh1r = fr + bh1r; gh1z = fz + bh1z; gh1n = fn + bh1n; }
+                }
+            }
+            PB(4);
+            {
+                u4v gx[NM];
+                gather_vec<NM>(mrs, (L::G_X3 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 23u);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const float2 x2v = *(const float2 *)(lds + L::L_P + pair_dst(m));
+                    const float x3a = __uint_as_float(gx[m].x), x3b = __uint_as_float(gx[m].z);
+                    *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(x3a, x3b);
+                    *(float2 *)(lds + L::L_H2 + pair_dst(m)) = make_float2(x3a - x2v.x, x3b - x2v.y);   // h2' = x3 - x2
+                }
+            }
+            PB(5);
+            __syncthreads();   // B2
+            PB(6);
+
+            // ================= window 3: phase C (fc1, :217-218) | gh2' = W_hh2 . h2' | gather fc1 outputs =================
+            {
+                f4 sum[NQ];
+                mfma_single<NQ, (NQ == 1 ? 4 : 2)>(wv + 288, vQ, lane, sum);
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float f = fold_kp(sum[q]);
+                    if (q == 0 || my_rq == q) s = f;
+                }
+                if (primary) st_granule(mail, L::G_F1 + par * L::RG + mb_own, epoch, __float_as_uint(fmaxf(s + c2.w, 0.0f)));
+            }
+            PB(7);
+            {
+                f4 acc[3][NQ];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
+                mfma_gates<NQ, 3>(wv + 192, vH2, lane, acc);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
+                    if (q == 0 || my_rq == q) { gh2r = fr + bh2r; gh2z = fz + bh2z; gh2n = fn + bh2n; }
+                }
+            }
+            PB(8);
+            {
+                u4v gx[NM];
+                gather_vec<NM>(mrs, (L::G_F1 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 24u);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
+            }
+            PB(9);
+            __syncthreads();   // B3
+
+            // ================= window 4: phase D (fc2, :220-221) | noise of this step, conditioning of the next | gather fc2 =================
+            {
+                f4 sum[NQ];
+                mfma_single<NQ, (NQ == 1 ? 4 : 2)>(wv + 320, vP, lane, sum);
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float f = fold_kp(sum[q]);
+                    if (q == 0 || my_rq == q) s = f;
+                }
+                if (primary) st_granule(mail, L::G_F2 + par * L::RG + mb_own, epoch, __float_as_uint(fmaxf(s + c4, 0.0f)));
+            }
+            PB(10);
+            prep_noise(t);
+            if (t + 1 < a.steps) prep_cond(t + 1);
+            {
+                u4v gx[NM];
+                gather_vec<NM>(mrs, (L::G_F2 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 25u);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
+            }
+            PB(11);
+            __syncthreads();   // B4
+
+            // ================= window 5: phase E (fc3 :223 + sampler :225-237) | race =================
+            {
+                float lg0 = 0.f, lg1 = 0.f;
+                if (wg_has_fc3) {
+                    constexpr int NP = NQ == 1 ? 2 : 1;
+                    f4 acc[2][NP][NQ];
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) acc[st][p][q] = (f4){0.f, 0.f, 0.f, 0.f};
+                    const f4 *w3 = (const f4 *)(lds + L::L_FC3) + (size_t)(wl * 2) * 8 * 64 + lane;
+#pragma unroll
+                    for (int S = 0; S < 8; ++S) {
+                        f4 b[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64 + lane];
+                        const f4 wa = w3[S * 64], wb = w3[(8 + S) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) {
+                                acc[0][e % NP][q] = mfma4(wa[e], b[q][e], acc[0][e % NP][q]);
+                                acc[1][e % NP][q] = mfma4(wb[e], b[q][e], acc[1][e % NP][q]);
+                            }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        f4 s0 = acc[0][0][q], s1 = acc[1][0][q];
+#pragma unroll
+                        for (int p = 1; p < NP; ++p) { s0 += acc[0][p][q]; s1 += acc[1][p][q]; }
+                        const float f0 = fold_kp(s0), f1 = fold_kp(s1);
+                        if (q == 0 || my_rq == q) { lg0 = f0; lg1 = f1; }
+                    }
+                    lg0 += b30; lg1 += b31;
+                    if (a.logits_out && primary && row_ok) {
+                        float *lo = a.logits_out + ((size_t)t * a.n_rows + row) * NC;
+                        if (cls0 < NC) lo[cls0] = lg0;
+                        if (cls0 + 4 < NC) lo[cls0 + 4] = lg1;
+                    }
+                }
+                if (MODE == WRNN_MODE_RAW) {
+                    // the race argmax_k logit_k - log q_k (:231-235): winner of this thread's 2 classes, then of the 8 classes
+                    // of the wave for the thread's batch row (fold over the 4 rows of 16 lanes), one granule per wave and row
+                    float v = cls0 < NC ? lg0 + nz0 : -INFINITY;
+                    int k = cls0;
+                    const float v1 = cls0 + 4 < NC ? lg1 + nz1 : -INFINITY;
+                    if (v1 > v) { v = v1; k = cls0 + 4; }
+                    {
+                        const u2v pv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                        const u2v pk = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+                        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
+                        const int ka = (int)pk.x, kb = (int)pk.y;
+                        const bool tb = vb > va || (vb == va && kb < ka);
+                        v = tb ? vb : va; k = tb ? kb : ka;
+                    }
+                    {
+                        const u2v pv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                        const u2v pk = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+                        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
+                        const int ka = (int)pk.x, kb = (int)pk.y;
+                        const bool tb = vb > va || (vb == va && kb < ka);
+                        v = tb ? vb : va; k = tb ? kb : ka;
+                    }
+                    if (primary && rho == 0)
+                        st_granule(mail, L::G_PR + par * L::PRG + (unsigned)rb * 128u + (unsigned)(g * 4 + wl),
+                                   (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
+                } else {
+                    // MOL: the 30 fc3 outputs of every batch row are published by workgroup 0
+                    if (wg_has_fc3 && primary) {
+                        if (cls0 < NC) st_granule(mail, L::G_PR + par * L::PRG + (unsigned)rb * 128u + (unsigned)cls0, epoch, __float_as_uint(lg0));
+                        if (cls0 + 4 < NC) st_granule(mail, L::G_PR + par * L::PRG + (unsigned)rb * 128u + (unsigned)(cls0 + 4), epoch, __float_as_uint(lg1));
+                    }
+                }
+            }
+            PB(12);
+            // ---- exchange 5: wave w finishes batch rows w, w + 4 ----
+#pragma unroll
+            for (int brow = wl; brow < R; brow += 4) {
+                const int rrow_raw = batch * a.rpb + brow;
+                const bool rok = brow < a.rpb && rrow_raw < a.n_rows;
+                const int rrow = rok ? rrow_raw : a.n_rows - 1;
+                float x_new;
+                int lab;
+                if (MODE == WRNN_MODE_RAW) {
+                    u4v gq = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)brow * 128u) * 8u + (unsigned)lane * 16u);
+                    unsigned spins = 0;
+                    const unsigned tg = epoch & 0x3fffffu;
+                    while (!dead && !__all((gq.y >> 10) == tg && (gq.w >> 10) == tg)) {
+                        if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 26u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        gq = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)brow * 128u) * 8u + (unsigned)lane * 16u);
+                    }
+                    const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
+                    const bool pb = vb > va;   // equal scores: the lower slot = the lower class range wins
+                    const float best = pb ? vb : va;
+                    const int besti = (int)((pb ? gq.w : gq.y) & 1023u);
+                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
+                    const u64 ball = __ballot(best == mx);
+                    const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
+                    lab = __builtin_amdgcn_readlane(besti, src);
+                    x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
+                } else {
+                    // sample_from_discretized_mix_logistic (distribution.py:87-123) for batch row `brow`
+                    const int nr = NC / 3;
+                    float nzv = 0.0f;
+                    if (lane <= nr) {
+                        float u;
+                        if (a.noise_mode == WRNN_NOISE_INJECTED)
+                            u = lane < nr ? a.noise1[((size_t)t * a.n_rows + rrow) * nr + lane] : a.noise2[(size_t)t * a.n_rows + rrow];
+                        else
+                            u = 1e-5f + wrnn_uniform(a.seed, (uint64_t)t, (uint32_t)rrow, (uint32_t)lane) * (1.0f - 2e-5f);
+                        nzv = lane < nr ? -logf(-logf(u)) : logf(u) - logf(1.0f - u);
+                    }
+                    float mylg = 0.0f;
+                    {
+                        const u64 *gp = mail + L::G_PR + par * L::PRG + (unsigned)brow * 128u + (unsigned)(lane < NC ? lane : 0);
+                        u64 gq = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned spins = 0;
+                        while (!dead && !__all((unsigned)(gq >> 32) == epoch)) {
+                            if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 27u); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                            gq = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        mylg = __uint_as_float((unsigned)gq);
+                    }
+                    const float v = lane < nr ? mylg + nzv : -INFINITY;
+                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(v)), 63));
+                    const u64 ball = __ballot(v == mx);
+                    const int km = (int)__builtin_ctzll(ball ? ball : 1ull);
+                    const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylg), nr + km));
+                    const float ls = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylg), 2 * nr + km)), -32.23619130191664f);
+                    const float nlog = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nzv), nr));
+                    x_new = fminf(fmaxf(mean + expf(ls) * nlog, -1.0f), 1.0f);
+                    lab = km;
+                }
+                if (lane == 0) {
+                    xn[brow] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + rrow] : x_new;   // (:237)
+                    if (g == 0 && rok) {
+                        if (a.labels_out) a.labels_out[(size_t)rrow * a.steps + t] = lab;
+                        a.samples_out[(size_t)rrow * a.steps + t] = x_new;
+                    }
+                }
+            }
+            PB(13);
+            __syncthreads();   // B5
+            PB(14);
+            if ((t & 63) == 63) {   // bounded-spin bail-out, checked workgroup-wide every 64 steps
+                if (dead && lane == 0) misc_i[M_DEAD] = 1;
+                __syncthreads();
+                if (misc_i[M_DEAD]) return;
+            }
+        }
+        __syncthreads();
+    }
+    if (PROF && a.prof && lane == 0 && g == 0 && team == 0) {
+        for (int i = 0; i < 16; ++i) a.prof[wl * 17 + i] += prof_acc[i];
+    }
+}
+
+template <int MODE, int NQ>
+static hipError_t launch_one(const WrnnBatchArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)Lay<NQ>::L_TOTAL * sizeof(float);
+    hipError_t e;
+    if (a.prof) {
+        e = hipFuncSetAttribute((const void *)loop_batch_kernel<MODE, NQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((loop_batch_kernel<MODE, NQ, true>), dim3(a.n_teams * TB_WGS), dim3(TB_THREADS), lds, s, a);
+    } else {
+        e = hipFuncSetAttribute((const void *)loop_batch_kernel<MODE, NQ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((loop_batch_kernel<MODE, NQ, false>), dim3(a.n_teams * TB_WGS), dim3(TB_THREADS), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+// a.nq = 1 (4 rows per team) or 2 (8 rows)
+hipError_t wrnn_launch_loop_batch(const WrnnBatchArgs &a, hipStream_t s) {
+    (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
+    if (a.d.mode == WRNN_MODE_RAW) return a.nq == 2 ? launch_one<WRNN_MODE_RAW, 2>(a, s) : launch_one<WRNN_MODE_RAW, 1>(a, s);
+    return a.nq == 2 ? launch_one<WRNN_MODE_MOL, 2>(a, s) : launch_one<WRNN_MODE_MOL, 1>(a, s);
+}
+
+// co-residency facts for wrnn_create's check: LDS bytes and the occupancy the runtime reports for the kernel
+hipError_t wrnn_batch_occupancy(int nq, int *blocks_per_cu, size_t *lds_bytes) {
+    const size_t lds = (size_t)(nq == 2 ? Lay<2>::L_TOTAL : Lay<1>::L_TOTAL) * sizeof(float);
+    *lds_bytes = lds;
+    const void *fn = nq == 2 ? (const void *)loop_batch_kernel<WRNN_MODE_RAW, 2, false> : (const void *)loop_batch_kernel<WRNN_MODE_RAW, 1, false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, TB_THREADS, lds);
+}

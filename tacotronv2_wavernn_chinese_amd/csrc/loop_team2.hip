@@ -1,6 +1,6 @@
 // WRNN_KERNEL_TEAM2: the per-sample loop (fatchord_version.py:194-241) with WAVE SPECIALISATION.
 //
-// Same team structure and exchange protocol as loop_team.hip (one team = the 32 workgroups of one XCD,
+// Team structure and exchange protocol (one team = the 32 workgroups of one XCD,
 // fp32 weights resident on chip, 8-byte {tag,value} granules through the XCD's L2, 4 exchanges on the critical
 // path + 1 off it, 5 workgroup barriers per step).  What changes is who does what inside a workgroup.
 //
@@ -545,7 +545,10 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 }
                 if (MODE == WRNN_MODE_RAW) {
                     // winner of this quarter-wave's 2 classes: argmax logit_k - log q_k
-                    const float v0 = lg0 + hand[4 + 2 * par], v1 = lg1 + hand[5 + 2 * par];
+                    // quarters beyond n_classes (bits < 10) own no class: they enter the race with -inf (and never read their
+                    // noise slot, which the shadow wave leaves unwritten for them)
+                    const float v0 = has_fc3 ? lg0 + hand[4 + 2 * par] : -INFINITY;
+                    const float v1 = (c3row0 + 1 < NC) ? lg1 + hand[5 + 2 * par] : -INFINITY;
                     const bool p1 = v1 > v0;
                     if (q == 0) st_granule(mail, G_PR + par * 512 + 16 * g + qslot,
                                            (epoch << 10) | (unsigned)(p1 ? c3row0 + 1 : c3row0), __float_as_uint(p1 ? v1 : v0));
@@ -669,22 +672,28 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
     }
 }
 
+hipError_t wrnn_team2_occupancy(int *blocks_per_cu, size_t *lds_bytes) {
+    const size_t lds = (size_t)L_TOTAL * sizeof(float);
+    *lds_bytes = lds;
+    const void *fn = (const void *)loop_team2_kernel<WRNN_MODE_RAW, false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, T2_THREADS, lds);
+}
+
 hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s) {
     (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
-    static bool attr_set = false;
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_RAW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_MOL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    if (a.prof && a.d.mode == WRNN_MODE_RAW) {
-        hipError_t e = hipFuncSetAttribute((const void *)loop_team2_kernel<WRNN_MODE_RAW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+    // the attribute is per device (function objects are per-device in the runtime): set it on every launch, it is a
+    // host-side table write
+    const void *fn = a.prof && a.d.mode == WRNN_MODE_RAW ? (const void *)loop_team2_kernel<WRNN_MODE_RAW, true>
+                     : a.d.mode == WRNN_MODE_RAW         ? (const void *)loop_team2_kernel<WRNN_MODE_RAW, false>
+                                                         : (const void *)loop_team2_kernel<WRNN_MODE_MOL, false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (a.prof && a.d.mode == WRNN_MODE_RAW)
         hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, true>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
-    } else if (a.d.mode == WRNN_MODE_RAW)
+    else if (a.d.mode == WRNN_MODE_RAW)
         hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, false>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
     else
         hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_MOL, false>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);

@@ -304,3 +304,58 @@ hipError_t wrnn_launch_cond_stream(const float *rec, const float *ktab, const Wr
     hipLaunchKernelGGL(cond_stream_kernel, grid, dim3(512), 0, s, rec, ktab, rows, (float4 *)cond, T, HOP, total_len, seg0, seg_len);
     return hipGetLastError();
 }
+
+// Batch kernel conditioning records: REC32[b][fi][j][32] = the 24 floats of pack_records_kernel (same slots) followed by
+// the per-frame constants of the layers behind phase A for hidden unit j: [24..26] C2[fi][r,z,n][j] (W_ih2[:,H:].a2 + b_ih2),
+// [27] C3[fi][j] (fc1), [28] C4[fi][j] (fc2), [29..31] pad.  One 128-byte record is everything a workgroup needs per
+// (frame, unit): the batch kernel reads 16 units x R rows of them per step instead of an 8 KB/step conditioning stream.
+__global__ void __launch_bounds__(256)
+pack_records32_kernel(const float *__restrict__ CM, const float *__restrict__ CA, const float *__restrict__ VM,
+                      const float *__restrict__ VA, const float *__restrict__ C2, const float *__restrict__ C3,
+                      const float *__restrict__ C4, float *__restrict__ rec, int T, int P) {
+    const int fi = blockIdx.x, b = blockIdx.y;
+    const int TP = T + 2 * P, T1 = T + 1;
+    const float *cm = CM + (size_t)b * TP * 512, *ca = CA + (size_t)b * T1 * 512;
+    const float *vm = VM + (size_t)b * TP * 1536, *va = VA + (size_t)b * T1 * 1536;
+    const float *c2 = C2 + (size_t)b * T1 * 1536, *c3 = C3 + (size_t)b * T1 * 512, *c4 = C4 + (size_t)b * T1 * 512;
+    float *out = rec + ((size_t)b * T1 + fi) * 512 * 32;
+    const bool live = fi < T;
+    for (int i = threadIdx.x; i < 512 * 32; i += blockDim.x) {
+        const int j = i >> 5, f = i & 31;
+        float v = 0.0f;
+        if (f == 0) v = ca[(size_t)fi * 512 + j];
+        else if (f < 4) v = va[(size_t)fi * 1536 + (f - 1) * 512 + j];
+        else if (f < 9) { if (live) v = cm[(size_t)(fi + f - 4) * 512 + j]; }
+        else if (f < 24) { const int dd = (f - 9) / 3, g = (f - 9) - 3 * dd; if (live) v = vm[(size_t)(fi + dd) * 1536 + g * 512 + j]; }
+        else if (f < 27) v = c2[(size_t)fi * 1536 + (f - 24) * 512 + j];
+        else if (f == 27) v = c3[(size_t)fi * 512 + j];
+        else if (f == 28) v = c4[(size_t)fi * 512 + j];
+        out[i] = v;
+    }
+}
+
+hipError_t wrnn_launch_pack_records32(const float *CM, const float *CA, const float *VM, const float *VA, const float *C2,
+                                      const float *C3, const float *C4, float *rec, int B, int T, int P, hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(pack_records32_kernel, dim3(T + 1, B), dim3(256), 0, s, CM, CA, VM, VA, C2, C3, C4, rec, T, P);
+    return hipGetLastError();
+}
+
+// The loop's row table, built on the device (no host staging buffer, no synchronisation in wrnn_generate):
+// unbatched: row r = utterance r from position 0; batched (fold_with_overlap :332-338): row r = utterance 0 from
+// position r * (target + overlap).
+__global__ void rows_kernel(WrnnRow *rows, int n_rows, int batched, long stride) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    WrnnRow w;
+    w.utt = batched ? 0 : r;
+    w.pad_ = 0;
+    w.start = batched ? (int64_t)r * stride : 0;
+    rows[r] = w;
+}
+
+hipError_t wrnn_launch_rows(WrnnRow *rows, int n_rows, int batched, long stride, hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, rows, n_rows, batched, stride);
+    return hipGetLastError();
+}

@@ -78,6 +78,9 @@ struct wrnn_handle {
     unsigned *err_dev = nullptr;  // device error word (bounded spins)
     // team kernel state
     float *team_w = nullptr, *team_fc3 = nullptr, *wI0 = nullptr, *u1 = nullptr;
+    float *batch_w = nullptr, *batch_fc3 = nullptr;   // batch kernel images of the same weights
+    bool team_ok = false;         // the 32-workgroup team kernels can be co-resident on this device (checked at create)
+    std::string team_why;         // why not, when team_ok is false
     float *tab = nullptr;         // CM|CA|VM|VA|C2|C3|C4 for the current batch
     size_t tab_cap = 0;
     float *cond = nullptr;        // conditioning stream of the current segment (TEAM2)
@@ -90,6 +93,7 @@ struct wrnn_handle {
     unsigned *ctl = nullptr;
     int n_teams = 8;              // XCDs (32-CU teams) of this device
     unsigned long long *prof = nullptr;   // set when WRNN_TEAM_PROF=1 in the environment
+    double prof_div = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
     wrnn_timing last{};
@@ -168,13 +172,55 @@ struct WrnnTeamArgs {
     unsigned long long *prof;  // [8][17] phase cycle counters (developer instrumentation) or null
 };
 
+// Batch kernel (loop_batch.hip): R = 4 * nq rows per team in lock-step on the matrix cores.
+// mailbox per team: 5 gathered vectors (x2, h1', x3, fc1, fc2) x 2 parities x R*512 granules + race 2 x R*128
+#define WRNN_BATCH_MAIL_GRANULES (10 * 8 * 512 + 2 * 8 * 128)
+#define WRNN_BATCH_MAX_ROWS 8
+#define WRNN_MAIL_GRANULES_MAX (WRNN_BATCH_MAIL_GRANULES > WRNN_TEAM_MAIL_GRANULES ? WRNN_BATCH_MAIL_GRANULES : WRNN_TEAM_MAIL_GRANULES)
+
+struct WrnnBatchArgs {
+    const float *w;           // packed weights (biases, ktab)
+    WrnnPacked off;
+    WrnnDims d;
+    const float *batch_w;     // [32 WGs][4 waves][352][64 lanes] MFMA A-operand images of the register-resident weights
+    const float *batch_fc3;   // [32 WGs][4 waves][2 sets][8][64 lanes][4] A-operand image of the fc3 slice (LDS)
+    const float *wI0;         // [H]   W_I[:,0]
+    const float *u1;          // [3H]  W_ih1 . W_I[:,0]
+    const float *tabREC32;    // (B, T+1, H, 32): the 24 phase-A record floats (pack_records_kernel) | c2 r,z,n | c3 | c4 | pad
+    const WrnnRow *rows;
+    int32_t n_rows;
+    int32_t n_teams;
+    int32_t nq;               // row quads per team: 1 (4 rows) or 2 (8 rows)
+    int32_t rpb;              // rows actually placed in one batch (<= 4 * nq): batch b = rows [b * rpb, (b + 1) * rpb)
+    int32_t T;
+    int64_t total_len;
+    int64_t steps;
+    int32_t noise_mode;
+    uint64_t seed;
+    const float *noise1;
+    const float *noise2;
+    const float *x_forced;
+    float *logits_out;
+    int32_t *labels_out;
+    float *samples_out;
+    unsigned long long *mail;  // [n_teams][WRNN_BATCH_MAIL_GRANULES]
+    unsigned *ctl;
+    unsigned *err;
+    unsigned long long *prof;
+};
+
 // kernels / launchers (defined in the .hip files)
 hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, float *aux_frames,
                               hipStream_t s);
 hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, const float *aux_frames, int B,
                                    int T, float *up, float *aux_up, hipStream_t s);
 hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
-hipError_t wrnn_launch_loop_team(const WrnnTeamArgs &a, hipStream_t s);
+hipError_t wrnn_launch_loop_batch(const WrnnBatchArgs &a, hipStream_t s);
+hipError_t wrnn_batch_occupancy(int nq, int *blocks_per_cu, size_t *lds_bytes);
+hipError_t wrnn_team2_occupancy(int *blocks_per_cu, size_t *lds_bytes);
+hipError_t wrnn_launch_rows(WrnnRow *rows, int n_rows, int batched, long stride, hipStream_t s);
+hipError_t wrnn_launch_pack_records32(const float *CM, const float *CA, const float *VM, const float *VA, const float *C2,
+                                      const float *C3, const float *C4, float *rec, int B, int T, int P, hipStream_t s);
 hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s);
 hipError_t wrnn_launch_cond_stream(const float *rec, const float *ktab, const WrnnRow *rows, float *cond, int n_rows, int T,
                                    int HOP, long total_len, long seg0, long seg_len, hipStream_t s);

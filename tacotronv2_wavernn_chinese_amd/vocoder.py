@@ -90,6 +90,7 @@ class WaveRNN(nn.Module):
         self.aux_dims = res_out_dims // 4
         self.hop_length = hop_length
         self.sample_rate = sample_rate
+        self.feat_dims = feat_dims
         self._ctor = dict(rnn_dims=rnn_dims, fc_dims=fc_dims, bits=bits, pad=pad,
                           upsample_factors=tuple(int(s) for s in upsample_factors), feat_dims=feat_dims,
                           compute_dims=compute_dims, res_out_dims=res_out_dims, res_blocks=res_blocks,
@@ -124,7 +125,15 @@ class WaveRNN(nn.Module):
         return torch.cuda.current_device()
 
     def _weights_key(self, dev: int):
-        return (dev,) + tuple((id(p), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """Cheap fingerprint of the parameters the native handle was packed from: identity, in-place version counter
+        and storage address of every tensor.  Catches ``load_state_dict``, optimizer steps, ``p.data = t`` (the idiom of
+        the reference's ``get_gru_cell``) and ``.to()``.  Writes through ``p.data`` that keep the storage
+        (``p.data.copy_()``, ``p.data.fill_()``) bump neither: call :meth:`invalidate_native` after those."""
+        return (dev,) + tuple((id(p), p._version, p.data_ptr()) for p in list(self.parameters()) + list(self.buffers()))
+
+    def invalidate_native(self):
+        """Force the next ``generate`` to repack the weights into the native handle."""
+        self._native_key = None
 
     def native(self) -> _cabi.NativeVocoder:
         """The wrnn_handle for the current device, repacked if parameters changed."""
@@ -137,7 +146,7 @@ class WaveRNN(nn.Module):
             self._native_key = None
         if self._native_key != key:
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
-            self._native.load_weights(sd, strict=True)
+            self._native.load_weights(sd)
             self._native_key = key
         return self._native
 
@@ -161,6 +170,8 @@ class WaveRNN(nn.Module):
             if mels_t.dim() != 3:
                 raise ValueError(f'expected mels shaped (B, n_mels, T), got {tuple(mels_t.shape)}')
             B, F, T = mels_t.shape
+            if F != self.feat_dims:   # the reference dies in conv_in with a channel mismatch (:43); a (T, n_mels) array lands here too
+                raise ValueError(f'expected mels shaped (B, {self.feat_dims}, T), got {tuple(mels_t.shape)}')
             rows, steps = nat.plan(B, T, batched, target, overlap)
             samples = torch.empty((rows, steps), dtype=torch.float32, device=dev)
             labels = torch.empty((rows, steps), dtype=torch.int32, device=dev)

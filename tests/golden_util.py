@@ -11,7 +11,10 @@ from oracle.noise import noise_checksum, noise_from_seed
 from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f[:4] in ('raw_', 'mol_'))   # dm_*: tests/test_deepmind.py
+# BASELINE-size fixtures (labels + wav only, oracle/make_golden.py LONG_CASES): their own tests, not the per-case sweeps
+LONG_CASES = ['raw_peaky_b1_t401', 'raw_peaky_b8_t60']
+ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f[:4] in ('raw_', 'mol_')
+                   and f[:-4] not in LONG_CASES)   # dm_*: tests/test_deepmind.py
 RAW_CASES = [c for c in ALL_CASES if c.startswith('raw_')]
 MOL_CASES = [c for c in ALL_CASES if c.startswith('mol_')]
 

@@ -63,3 +63,24 @@ def check_mol(got_samples, got_mix, ref, teacher_forced):
         # well inside one 9-bit LSB.
         tol = 2e-5 if teacher_forced else MOL_LSB / 4
         assert err.size == 0 or err.max() <= tol, f'row {r}: max sample error {err.max():.3e} (tol {tol:.1e})'
+
+
+def label_stats(got, ref_labels, first):
+    """What the north star's "+-1 LSB at 10 bit" contract looks like on a run: `got`, `ref_labels` (L, rows); `first` =
+    check_free_run_raw's list of first-divergence steps.  Returns the number of steps compared (every step of a row up
+    to its first near-tie divergence, exclusive; everything if it never diverges), the mismatches among them, their
+    max |label difference| (0 = the fed-back values are bit-identical), and |label difference| AT the near-tie steps
+    (a near-tie picks the runner-up class of the race, which need not be an adjacent class)."""
+    compared = mism = max_abs = 0
+    near = []
+    for r in range(got.shape[1]):
+        end = got.shape[0] if first[r] is None else int(first[r])
+        d = np.abs(got[:end, r].astype(np.int64) - ref_labels[:end, r].astype(np.int64))
+        compared += end
+        mism += int(np.count_nonzero(d))
+        if d.size:
+            max_abs = max(max_abs, int(d.max()))
+        if first[r] is not None:
+            t = int(first[r])
+            near.append(int(abs(int(got[t, r]) - int(ref_labels[t, r]))))
+    return dict(compared=compared, mismatches=mism, max_abs=max_abs, near_tie_abs=near)

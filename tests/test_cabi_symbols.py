@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     lib = _cabi.load_library()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.wrnn_abi_version() == 2
+    assert lib.wrnn_abi_version() == 3
 
 
 def test_create_rejects_bad_config_without_gpu():

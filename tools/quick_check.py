@@ -23,7 +23,7 @@ def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 41
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     modes = ('RAW',) if len(sys.argv) > 3 and sys.argv[3] == 'raw' else ('RAW', 'MOL')
-    kernels = (('team2', _cabi.KERNEL_TEAM2),) if len(sys.argv) > 4 and sys.argv[4] == 'team2' else (('team', _cabi.KERNEL_TEAM), ('team2', _cabi.KERNEL_TEAM2)) if len(sys.argv) > 4 and sys.argv[4] == 'team' else (('simple', _cabi.KERNEL_SIMPLE), ('team', _cabi.KERNEL_TEAM), ('team2', _cabi.KERNEL_TEAM2))
+    kernels = (('team2', _cabi.KERNEL_TEAM2),) if len(sys.argv) > 4 and sys.argv[4] == 'team2' else (('batch', _cabi.KERNEL_BATCH), ('team2', _cabi.KERNEL_TEAM2)) if len(sys.argv) > 4 and sys.argv[4] == 'batch' else (('simple', _cabi.KERNEL_SIMPLE), ('batch', _cabi.KERNEL_BATCH), ('team2', _cabi.KERNEL_TEAM2))
     for mode in modes:
         m = model(mode)
         mels = make_mels(3, B, T)
