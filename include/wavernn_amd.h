@@ -111,6 +111,15 @@ typedef struct wrnn_sample_opts {
     const float *x_forced_dev;
     /* optional dump of the fc3 outputs, (L, rows, n_classes) device or NULL */
     float *logits_out_dev;
+    /* value fed to step 0 of every row instead of 0 (:196), (rows) device pointer or NULL.  With x_forced_dev this is
+     * the teacher-forced pass of WaveRNN.forward (fatchord_version.py:131-167): input sequence x[0..L) = x_init,
+     * x_forced[0..L-1), logits in logits_out_dev. */
+    const float *x_init_dev;
+    /* != 0: mels_dev is (B, feat, T + 2*pad), already padded by `pad` frames on both sides with real context like the
+     * training collate does and WaveRNN.forward receives it (:143); 0: (B, feat, T), zero padding applied on the fly
+     * like generate() (:183-185).  T is the unpadded frame count either way. */
+    int32_t mels_padded;
+    int32_t reserved_;
 } wrnn_sample_opts;
 
 typedef struct wrnn_timing {
@@ -135,9 +144,10 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
 /* Conditioning exactly as generate() builds it (fatchord_version.py:183-186:
  * pad_tensor 'both' + UpsampleNetwork.forward :82-89), materialised:
  *   mels_dev (B, feat, T) -> up_dev (B, T*hop, feat), aux_dev (B, T*hop, res_out)
+ * mels_padded != 0: mels_dev is (B, feat, T + 2*pad) as WaveRNN.forward receives it (see wrnn_sample_opts).
  * Either output may be NULL.  Used by parity tests of the prologue; the loop
  * itself never materialises these tensors. */
-int wrnn_conditioning(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, float *up_dev,
+int wrnn_conditioning(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, int32_t mels_padded, float *up_dev,
                       float *aux_dev, void *stream);
 
 /* Number of loop rows / steps generate() will run for (B, T, batched, target,
@@ -170,6 +180,14 @@ int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int32_t *label
  * NULL when overlap == 0), tail[20*hop] (np.linspace(1, 0, 20*hop_length), :256).  Caller-allocated. */
 int wrnn_epilogue_tables(int32_t n_classes, int32_t overlap, int32_t hop, double *dec, double *fade_in, double *fade_out,
                          double *tail);
+
+/* The loss the reference's training script applies to WaveRNN.forward's output (wavernn_train.py:82,112-121), forward value
+ * only.  y_hat_dev (n_rows, n_classes) = the fc3 outputs of n_rows = B*L (batch, step) pairs, row-major.
+ *   RAW model: F.cross_entropy -- y_dev = int32 class labels (n_rows); a label outside [0, n_classes) gives NaN.
+ *   MOL model: discretized_mix_logistic_loss (wavernn/utils/distribution.py:16-84; num_classes 65536,
+ *              log_scale_min log(1e-14), reduce=True) -- y_dev = float32 targets in [-1, 1] (n_rows).
+ * loss_out_dev: one float32 on the device.  Asynchronous on `stream`. */
+int wrnn_loss(wrnn_handle *h, const float *y_hat_dev, const void *y_dev, int64_t n_rows, float *loss_out_dev, void *stream);
 
 /* Blocks until the last wrnn_generate on this handle finished, then reports
  * HIP-event timings and any device-side error (WRNN_ERR_TIMEOUT). */

@@ -40,12 +40,48 @@ LONG_CASES = [
     dict(name='raw_peaky_b1_t401', mode='RAW', bits=10, variant='peaky', B=1, T=401, batched=False, slim=True),
     dict(name='raw_peaky_b8_t60', mode='RAW', bits=10, variant='peaky', B=8, T=60, batched=False, slim=True),
 ]
+# Teacher-forced forward() + loss (`python -m oracle.make_golden forward`): N4 of SURVEY.md 8f
+FORWARD_CASES = [
+    dict(name='fwd_raw_peaky_b2_t6', mode='RAW', bits=10, variant='peaky', B=2, T=6),
+    dict(name='fwd_mol_default_b2_t6', mode='MOL', bits=9, variant='default', B=2, T=6),
+]
 WEIGHT_SEED, MEL_SEED, NOISE_SEED = 0, 1234, 42
+
+
+def mint_forward():
+    from oracle import ref_harness as rh
+    for c in FORWARD_CASES:
+        sd = make_state_dict(WEIGHT_SEED, mode=c['mode'], variant=c['variant'], bits=c['bits'])
+        model = rh.build_reference_model(sd, mode=c['mode'], bits=c['bits'])
+        B, T, pad, hop = c['B'], c['T'], 2, 275
+        L = T * hop
+        mels = make_mels(MEL_SEED, B, T + 2 * pad)          # the padded window the training collate hands over
+        rng = np.random.Generator(np.random.PCG64(NOISE_SEED))
+        if c['mode'] == 'RAW':
+            y = rng.integers(0, 1024, size=(B, L)).astype(np.int64)
+            x = (2.0 * rng.integers(0, 1024, size=(B, L)) / 1023.0 - 1.0).astype(np.float32)
+        else:
+            y = rng.uniform(-1.0, 1.0, size=(B, L)).astype(np.float32)
+            y[0, :7] = [-1.0, -0.9995, 0.9995, 1.0, 0.0, 0.5, -0.5]   # the edge branches of the discretised likelihood
+            x = rng.uniform(-1.0, 1.0, size=(B, L)).astype(np.float32)
+        out = rh.reference_forward(model, x, mels, y)
+        sub = slice(0, L, 23)
+        import torch
+        loss_sub = out['loss_of'](torch.from_numpy(np.ascontiguousarray(out['logits'][:, sub])), y[:, sub])
+        fix = dict(mode=c['mode'], bits=c['bits'], variant=c['variant'], B=B, T=T, weight_seed=WEIGHT_SEED, mel_seed=MEL_SEED,
+                   xy_seed=NOISE_SEED, x=x, y=y, logits_sub=out['logits'][:, sub].astype(np.float32), sub_stride=23,
+                   loss=np.float64(out['loss']), loss_sub=np.float64(loss_sub))
+        path = os.path.join(GOLDEN_DIR, c['name'] + '.npz')
+        np.savez_compressed(path, **fix)
+        print(f"{c['name']}: logits {out['logits'].shape} loss {out['loss']:.6f} loss_sub {loss_sub:.6f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def main() -> int:
     from oracle import ref_harness as rh
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'forward':
+        mint_forward()
+        return 0
     cases = LONG_CASES if (len(sys.argv) > 1 and sys.argv[1] == 'long') else CASES
     for c in cases:
         sd = make_state_dict(WEIGHT_SEED, mode=c['mode'], variant=c['variant'], bits=c['bits'])

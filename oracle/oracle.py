@@ -300,3 +300,52 @@ def epilogue(samples_bl: np.ndarray, n_classes: int, mu_law: bool, batched: bool
     out = out[:wave_len]
     out[-20 * hop_length:] *= fade  # raises ValueError for T < 21, like the reference
     return out
+
+
+# ------------------------------------------------ losses on forward()'s output (wavernn_train.py:82,112-121)
+
+def cross_entropy(y_hat: np.ndarray, y: np.ndarray) -> float:
+    """F.cross_entropy(y_hat.transpose(1, 2).unsqueeze(-1), y.unsqueeze(-1)): mean over (B, L) of
+    logsumexp(y_hat[b, t]) - y_hat[b, t, y[b, t]]; float32 per element, float64 mean."""
+    yh = np.asarray(y_hat, np.float32).reshape(-1, y_hat.shape[-1])
+    yy = np.asarray(y).reshape(-1).astype(np.int64)
+    m = yh.max(axis=1, keepdims=True)
+    lse = (m[:, 0] + np.log(np.exp(yh - m).sum(axis=1, dtype=np.float32))).astype(np.float32)
+    return float((lse - yh[np.arange(yh.shape[0]), yy]).astype(np.float64).mean())
+
+
+def _softplus(x):
+    x = np.asarray(x, np.float32)
+    with np.errstate(over='ignore'):
+        return np.where(x > 20.0, x, np.log1p(np.exp(np.minimum(x, 20.0)))).astype(np.float32)   # F.softplus(beta=1, threshold=20)
+
+
+def discretized_mix_logistic_loss(y_hat: np.ndarray, y: np.ndarray, num_classes: int = 65536,
+                                  log_scale_min: float = float(np.log(1e-14))) -> float:
+    """wavernn/utils/distribution.py:16-84 with reduce=True.  y_hat (B, L, 3*nr_mix), y (B, L) in [-1, 1]."""
+    yh = np.asarray(y_hat, np.float32)
+    nr = yh.shape[-1] // 3
+    logit_probs, means = yh[..., :nr], yh[..., nr:2 * nr]
+    log_scales = np.maximum(yh[..., 2 * nr:3 * nr], np.float32(log_scale_min))       # :31
+    yy = np.asarray(y, np.float32)[..., None]
+    cy = yy - means                                                                    # :36
+    inv = np.exp(-log_scales)
+    hb = np.float32(1.0 / (num_classes - 1))
+    plus_in, min_in = inv * (cy + hb), inv * (cy - hb)
+    sig = lambda v: (1.0 / (1.0 + np.exp(-v))).astype(np.float32)
+    cdf_delta = sig(plus_in) - sig(min_in)                                             # :39-54
+    log_cdf_plus = plus_in - _softplus(plus_in)                                        # :45
+    log_one_minus_cdf_min = -_softplus(min_in)                                         # :49
+    mid_in = inv * cy
+    log_pdf_mid = mid_in - log_scales - 2.0 * _softplus(mid_in)                        # :57
+    c2 = (cdf_delta > 1e-5).astype(np.float32)                                         # :68-72
+    inner_inner = c2 * np.log(np.maximum(cdf_delta, np.float32(1e-12))) + (1.0 - c2) * (log_pdf_mid - np.float32(np.log((num_classes - 1) / 2)))
+    c1 = (yy > 0.999).astype(np.float32)
+    inner = c1 * log_one_minus_cdf_min + (1.0 - c1) * inner_inner
+    c0 = (yy < -0.999).astype(np.float32)
+    log_probs = c0 * log_cdf_plus + (1.0 - c0) * inner
+    lm = logit_probs.max(axis=-1, keepdims=True)
+    log_probs = log_probs + (logit_probs - (lm + np.log(np.exp(logit_probs - lm).sum(axis=-1, keepdims=True, dtype=np.float32))))   # :77
+    m = log_probs.max(axis=-1, keepdims=True)
+    lse = m[..., 0] + np.log(np.exp(log_probs - m).sum(axis=-1, dtype=np.float32))     # log_sum_exp :6-12
+    return float(-(lse.astype(np.float64)).mean())

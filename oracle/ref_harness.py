@@ -154,6 +154,27 @@ def reference_generate(model, mels: np.ndarray, seed: int, batched: bool = False
     return out
 
 
+def reference_forward(model, x: np.ndarray, mels_padded: np.ndarray, y: np.ndarray) -> dict:
+    """The unmodified ``forward`` (fatchord_version.py:131-167) in eval mode (BatchNorm on its running statistics, as
+    in ``generate``) and the loss ``wavernn_train.py:82,112-121`` applies to it.  x (B, L) float32, mels_padded
+    (B, n_mels, T + 2*pad), y (B, L) int64 labels (RAW) / float32 targets (MOL)."""
+    import torch
+    import torch.nn.functional as F
+    ref = load_reference()
+    model.eval()
+    with torch.no_grad():
+        y_hat = model(torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(mels_padded)))
+
+        def loss_of(yh, yy):
+            yy = torch.from_numpy(np.ascontiguousarray(yy))
+            if model.mode == 'RAW':
+                return float(F.cross_entropy(yh.transpose(1, 2).unsqueeze(-1), yy.long().unsqueeze(-1)))
+            return float(ref.dist.discretized_mix_logistic_loss(yh, yy.float().unsqueeze(-1)))
+        out = dict(logits=y_hat.numpy(), loss=loss_of(y_hat, y), loss_of=loss_of)
+    model.train()
+    return out
+
+
 def replay_noise(seed: int, mode: str, steps: int, rows: int, n_classes: int = 1024,
                  rnn_dims: int = 512, aux_dims: int = 32) -> dict:
     """See oracle/noise.py (kept there so the GPU box can replay without the reference)."""

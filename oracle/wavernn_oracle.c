@@ -277,7 +277,7 @@ int wo_loop(const wo_dims *d, const wo_weights *w, const float *cond_m, const fl
     float *h1 = (float *)calloc((size_t)B * H, sizeof(float));   /* :194 */
     float *h2 = (float *)calloc((size_t)B * H, sizeof(float));   /* :195 */
     float *xprev = (float *)calloc((size_t)B, sizeof(float));    /* :196 */
-    float *cat = (float *)malloc((size_t)(H + A + in_I) * sizeof(float));
+    float *cat = (float *)malloc((size_t)((H > FC ? H : FC) + A + in_I) * sizeof(float));   /* holds [x | a] of every layer */
     float *x = (float *)malloc((size_t)H * sizeof(float));
     float *gi = (float *)malloc((size_t)3 * H * sizeof(float));
     float *gh = (float *)malloc((size_t)3 * H * sizeof(float));

@@ -27,7 +27,7 @@ ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN
 # every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
-                    'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_tables',
+                    'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_tables', 'wrnn_loss',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
                     'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
 
@@ -67,7 +67,7 @@ class TensorDesc(C.Structure):
 class SampleOpts(C.Structure):
     _fields_ = [('noise_mode', C.c_int32), ('kernel', C.c_int32), ('seed', C.c_uint64),
                 ('noise1_dev', C.c_void_p), ('noise2_dev', C.c_void_p), ('x_forced_dev', C.c_void_p),
-                ('logits_out_dev', C.c_void_p)]
+                ('logits_out_dev', C.c_void_p), ('x_init_dev', C.c_void_p), ('mels_padded', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -114,7 +114,7 @@ def load_library() -> C.CDLL:
     lib.wrnn_create.restype = C.c_int
     lib.wrnn_load_weights.argtypes = [vp, C.POINTER(TensorDesc), C.c_int32]
     lib.wrnn_load_weights.restype = C.c_int
-    lib.wrnn_conditioning.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.wrnn_conditioning.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     lib.wrnn_conditioning.restype = C.c_int
     lib.wrnn_plan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                               C.POINTER(C.c_int64)]
@@ -127,6 +127,8 @@ def load_library() -> C.CDLL:
     lib.wrnn_epilogue.restype = C.c_int
     lib.wrnn_epilogue_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.wrnn_epilogue_tables.restype = C.c_int
+    lib.wrnn_loss.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+    lib.wrnn_loss.restype = C.c_int
     lib.wrnn_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.wrnn_last_timing.restype = C.c_int
     lib.wrnn_n_classes.argtypes = [vp]
@@ -234,18 +236,20 @@ class NativeVocoder:
                                        C.byref(rows), C.byref(steps)))
         return rows.value, steps.value
 
-    def conditioning(self, mels_ptr: int, B: int, T: int, up_ptr: int, aux_ptr: int, stream: int):
-        self._check(self.lib.wrnn_conditioning(self._h, mels_ptr, B, T, up_ptr or None, aux_ptr or None,
+    def conditioning(self, mels_ptr: int, B: int, T: int, up_ptr: int, aux_ptr: int, stream: int, mels_padded: bool = False):
+        self._check(self.lib.wrnn_conditioning(self._h, mels_ptr, B, T, int(bool(mels_padded)), up_ptr or None, aux_ptr or None,
                                                stream or None))
 
     def generate(self, mels_ptr: int, B: int, T: int, batched: bool, target: int, overlap: int, *,
                  labels_ptr: int, samples_ptr: int, stream: int, noise_mode: int = NOISE_PHILOX, seed: int = 0,
                  noise1_ptr: int = 0, noise2_ptr: int = 0, x_forced_ptr: int = 0, logits_ptr: int = 0,
-                 kernel: int = KERNEL_AUTO):
+                 kernel: int = KERNEL_AUTO, x_init_ptr: int = 0, mels_padded: bool = False):
         o = SampleOpts()
         o.noise_mode, o.kernel, o.seed = noise_mode, kernel, seed & 0xFFFFFFFFFFFFFFFF
         o.noise1_dev, o.noise2_dev = noise1_ptr or None, noise2_ptr or None
         o.x_forced_dev, o.logits_out_dev = x_forced_ptr or None, logits_ptr or None
+        o.x_init_dev = x_init_ptr or None
+        o.mels_padded = int(bool(mels_padded))
         self._check(self.lib.wrnn_generate(self._h, mels_ptr, B, T, int(bool(batched)), int(target), int(overlap),
                                            C.byref(o), labels_ptr or None, samples_ptr, stream or None))
 
@@ -254,6 +258,9 @@ class NativeVocoder:
         self._check(self.lib.wrnn_epilogue(self._h, samples_ptr, labels_ptr or None, rows, steps, int(bool(batched)),
                                            int(target), int(overlap), int(bool(mu_law)), int(wave_len), out_ptr,
                                            stream or None))
+
+    def loss(self, y_hat_ptr: int, y_ptr: int, n_rows: int, out_ptr: int, stream: int):
+        self._check(self.lib.wrnn_loss(self._h, y_hat_ptr, y_ptr, int(n_rows), out_ptr, stream or None))
 
     def last_timing(self) -> dict:
         t = Timing()

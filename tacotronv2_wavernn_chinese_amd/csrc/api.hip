@@ -96,13 +96,19 @@ int wrnn_create(const wrnn_config *cfg, wrnn_handle **out) {
     else if (cfg->mode == WRNN_MODE_MOL) d.NC = 30;             // :100-101
     else { delete h; return WRNN_ERR_INVALID; }
     *out = h;  // from here on errors are reported through the handle
-    // Shapes this round's kernels are written for (the reference hparams, wavernn_hparams.py:18-57).
-    if (d.H != 512 || d.FC != 512 || d.F != 80 || d.R != 128 || d.C != 128 || d.A != 32)
-        return fail(h, WRNN_ERR_INVALID, "unsupported dims: kernels are built for rnn=fc=512, feat=80, compute=res_out=128");
+    // Any constructor dims (fatchord_version.py:93-129) run on the SIMPLE kernel as long as its activation vectors fit a
+    // CU's LDS; the team kernels (TEAM2, BATCH) are built for the reference hparams (wavernn_hparams.py:18-57).
+    if (d.H < 1 || d.FC < 1 || d.F < 1 || d.C < 1 || d.R < 4 || d.NBLK < 0 || d.P < 0 || cfg->bits < 1 || cfg->bits > 16)
+        return fail(h, WRNN_ERR_INVALID, "bad dims");
+    if (cfg->res_out_dims % 4 != 0) return fail(h, WRNN_ERR_INVALID, "res_out_dims must be a multiple of 4 (aux split, :109)");
+    if (d.H > 1024 || d.C > 1024 || d.R > 1024)
+        return fail(h, WRNN_ERR_INVALID, "unsupported dims: rnn_dims, compute_dims, res_out_dims up to 1024");
+    h->team_dims = d.H == 512 && d.FC == 512 && d.F == 80 && d.R == 128 && d.C == 128 && d.A == 32;
     if (hop != cfg->hop_length) return fail(h, WRNN_ERR_INVALID, "prod(upsample_factors)=%d != hop_length=%d", hop, cfg->hop_length);
     if (reach > cfg->pad * hop || d.ND > WRNN_KTAB_MAXD)
         return fail(h, WRNN_ERR_INVALID, "upsample edge reach %d exceeds indent %d: composite FIR not shift-invariant", reach, cfg->pad * hop);
-    if (d.NC > 1024) return fail(h, WRNN_ERR_INVALID, "n_classes %d > 1024 unsupported", d.NC);
+    if (wrnn_simple_lds_bytes(d) > 160u * 1024u || ((size_t)(8 + d.KS - 1) * d.F + 16u * d.C) * sizeof(float) > 160u * 1024u)
+        return fail(h, WRNN_ERR_INVALID, "dims too large: the activation vectors of one row (%zu bytes) must fit 160 KB of LDS", wrnn_simple_lds_bytes(d));
     HIP_TRY(h, hipSetDevice(cfg->device));
     {
         // team kernels: one team per XCD = 32 CUs (SPX: 256 CUs = 8 teams; a CPX/DPX partition exposes fewer)
@@ -116,7 +122,8 @@ int wrnn_create(const wrnn_config *cfg, wrnn_handle **out) {
         // one per CU (they take most of a CU's LDS).  Establish that here, loudly, instead of discovering it as a
         // bounded-spin timeout: the runtime must admit >= 1 workgroup per CU for every team kernel.
         h->team_ok = true;
-        if (h->n_teams < 1) { h->team_ok = false; h->team_why = "fewer than 32 CUs visible (one team = the 32 CUs of an XCD)"; }
+        if (!h->team_dims || d.NC > 1024) { h->team_ok = false; h->team_why = "the team kernels are built for rnn=fc=512, feat=80, compute=res_out=128, n_classes <= 1024"; }
+        else if (h->n_teams < 1) { h->team_ok = false; h->team_why = "fewer than 32 CUs visible (one team = the 32 CUs of an XCD)"; }
         int blocks = 0;
         size_t lds = 0;
         if (h->team_ok) {
@@ -146,12 +153,14 @@ void wrnn_destroy(wrnn_handle *h) {
     if (h->team_fc3) (void)hipFree(h->team_fc3);
     if (h->batch_w) (void)hipFree(h->batch_w);
     if (h->batch_fc3) (void)hipFree(h->batch_fc3);
+    if (h->batch_wn) (void)hipFree(h->batch_wn);
     if (h->wI0) (void)hipFree(h->wI0);
     if (h->u1) (void)hipFree(h->u1);
     if (h->tab) (void)hipFree(h->tab);
     if (h->cond) (void)hipFree(h->cond);
     if (h->team_state) (void)hipFree(h->team_state);
     if (h->epi_tab) (void)hipFree(h->epi_tab);
+    if (h->loss_partial) (void)hipFree(h->loss_partial);
     if (h->mail) (void)hipFree(h->mail);
     if (h->ctl) (void)hipFree(h->ctl);
     for (int i = 0; i < 3; ++i)
@@ -294,7 +303,8 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
     // hot-loop parameter bytes as the reference counts them: weights + biases, fp32
     h->loop_weight_bytes = 4LL * ((int64_t)H * IN_I + H + 2LL * 3 * H * H + 2LL * 3 * H + 3LL * H * (H + A) + 3LL * H * H + 2LL * 3 * H +
                                   (int64_t)FC * (H + A) + FC + (int64_t)FC * (FC + A) + FC + (int64_t)NC * FC + NC);
-    // ---- team kernel layouts (loop_team.hip): register-resident slices per (WG g, thread) -----
+    if (h->team_dims && NC <= 1024) {
+    // ---- team kernel layouts (loop_team2.hip): register-resident slices per (WG g, thread) -----
     // thread tid = wave*64 + r4*16 + q of WG g owns unit u = 16g + 4*wave + r4, columns 32q..32q+31
     const int TT = WRNN_TEAM_THREADS;
     std::vector<float> tw((size_t)32 * WRNN_TEAM_NWREG * TT), tf3((size_t)32 * 16384, 0.0f), vwI0(H), vu1(3 * H);
@@ -337,7 +347,7 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
     }
     // ---- batch kernel layouts (loop_batch.hip): MFMA 4x4x1 A-operand images.  Lane (kp = lane>>2, i = lane&3) of wave
     // wl of WG g holds W[row(16g + 4wl + i)][k], k = 64 S + 16 e + kp for register slab s = 4 S + e.
-    std::vector<float> bw((size_t)32 * 4 * 352 * 64, 0.0f), bf3((size_t)32 * 16384, 0.0f);
+    std::vector<float> bw((size_t)32 * 4 * 320 * 64, 0.0f), bf3((size_t)32 * 16384, 0.0f), bwn((size_t)32 * 8192, 0.0f);
     {
         const float *whh1 = tv["rnn1.weight_hh_l0"].f(), *wih2 = tv["rnn2.weight_ih_l0"].f(), *whh2 = tv["rnn2.weight_hh_l0"].f();
         const float *wfc1 = tv["fc1.weight"].f(), *wfc2 = tv["fc2.weight"].f(), *wfc3 = tv["fc3.weight"].f();
@@ -346,18 +356,19 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
                 for (int lane = 0; lane < 64; ++lane) {
                     const int kp = lane >> 2, i = lane & 3;
                     const int u = 16 * g + 4 * wl + i;
-                    // register r of the wave: W_ih2 r,z,n [0,96) | W_hh1 [96,192) | W_hh2 [192,288) | fc1 [288,320) | fc2 [320,352)
-                    auto at = [&](int r) -> float & { return bw[(((size_t)g * 4 + wl) * 352 + r) * 64 + lane]; };
+                    // register r of the wave: W_ih2 r,z,n [0,96) | W_hh1 r,z,n [96,192) | W_hh2 r,z [192,256) | fc1 [256,288) | fc2 [288,320)
+                    auto at = [&](int r) -> float & { return bw[(((size_t)g * 4 + wl) * 320 + r) * 64 + lane]; };
                     for (int s2 = 0; s2 < 32; ++s2) {
                         const int k = 64 * (s2 >> 2) + 16 * (s2 & 3) + kp;
                         for (int gate = 0; gate < 3; ++gate) {
                             const size_t row = (size_t)gate * H + u;
                             at(gate * 32 + s2) = wih2[row * (H + A) + k];
                             at(96 + gate * 32 + s2) = whh1[row * H + k];
-                            at(192 + gate * 32 + s2) = whh2[row * H + k];
+                            if (gate < 2) at(192 + gate * 32 + s2) = whh2[row * H + k];
+                            else bwn[(size_t)g * 8192 + ((size_t)(wl * 8 + (s2 >> 2)) * 64 + lane) * 4 + (s2 & 3)] = whh2[row * H + k];   // LDS image
                         }
-                        at(288 + s2) = wfc1[(size_t)u * (H + A) + k];
-                        at(320 + s2) = wfc2[(size_t)u * (FC + A) + k];
+                        at(256 + s2) = wfc1[(size_t)u * (H + A) + k];
+                        at(288 + s2) = wfc2[(size_t)u * (FC + A) + k];
                         for (int set = 0; set < 2; ++set) {
                             const int row = 32 * g + 8 * wl + 4 * set + i;
                             if (row < NC)
@@ -374,7 +385,9 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
         return WRNN_OK;
     };
     if ((rc = upload(h->team_w, tw)) || (rc = upload(h->team_fc3, tf3)) || (rc = upload(h->wI0, vwI0)) || (rc = upload(h->u1, vu1)) ||
-        (rc = upload(h->batch_w, bw)) || (rc = upload(h->batch_fc3, bf3))) return rc;
+        (rc = upload(h->batch_w, bw)) || (rc = upload(h->batch_fc3, bf3)) || (rc = upload(h->batch_wn, bwn))) return rc;
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!h->mail) {
         HIP_TRY(h, hipMalloc(&h->mail, (size_t)8 * WRNN_MAIL_GRANULES_MAX * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->ctl, 128));
@@ -398,14 +411,15 @@ static int ensure_aux(wrnn_handle *h, int B, int T) {
     return WRNN_OK;
 }
 
-int wrnn_conditioning(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, float *up_dev, float *aux_dev, void *stream) {
+int wrnn_conditioning(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, int32_t mels_padded, float *up_dev, float *aux_dev, void *stream) {
     if (!h || !mels_dev || B < 1 || T < 1) return fail(h, WRNN_ERR_INVALID, "wrnn_conditioning: bad arguments");
     if (!h->loaded) return fail(h, WRNN_ERR_STATE, "weights not loaded");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     if (int rc = ensure_aux(h, B, T)) return rc;
-    HIP_TRY(h, wrnn_launch_resnet(h, mels_dev, B, T, h->aux_frames, s));
-    if (up_dev || aux_dev) HIP_TRY(h, wrnn_launch_materialize(h, mels_dev, h->aux_frames, B, T, up_dev, aux_dev, s));
+    const int mel_T = mels_padded ? T + 2 * h->d.P : T, mel_off = mels_padded ? h->d.P : 0;
+    HIP_TRY(h, wrnn_launch_resnet(h, mels_dev, B, T, mel_T, mel_off, h->aux_frames, s));
+    if (up_dev || aux_dev) HIP_TRY(h, wrnn_launch_materialize(h, mels_dev, h->aux_frames, B, T, mel_T, mel_off, up_dev, aux_dev, s));
     return WRNN_OK;
 }
 
@@ -461,14 +475,15 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     HIP_TRY(h, hipMemsetAsync(h->err_dev, 0, 64, s));
 
     HIP_TRY(h, hipEventRecord(h->ev[0], s));
-    HIP_TRY(h, wrnn_launch_resnet(h, mels_dev, B, T, h->aux_frames, s));
+    const int mel_T = opts->mels_padded ? T + 2 * d.P : T, mel_off = opts->mels_padded ? d.P : 0;
+    HIP_TRY(h, wrnn_launch_resnet(h, mels_dev, B, T, mel_T, mel_off, h->aux_frames, s));
     HIP_TRY(h, hipEventRecord(h->ev[1], s));
 
     WrnnLoopArgs a{};
-    a.w = h->wdev; a.off = h->off; a.d = d; a.mels = mels_dev; a.aux_frames = h->aux_frames; a.rows = h->rows_dev;
+    a.w = h->wdev; a.off = h->off; a.d = d; a.mels = mels_dev; a.mel_T = mel_T; a.mel_off = mel_off; a.aux_frames = h->aux_frames; a.rows = h->rows_dev;
     a.n_rows = rows; a.T = T; a.total_len = (int64_t)T * d.HOP; a.steps = steps;
     a.noise_mode = opts->noise_mode; a.seed = opts->seed; a.noise1 = opts->noise1_dev; a.noise2 = opts->noise2_dev;
-    a.x_forced = opts->x_forced_dev; a.logits_out = opts->logits_out_dev; a.labels_out = labels_out_dev;
+    a.x_forced = opts->x_forced_dev; a.x_init = opts->x_init_dev; a.logits_out = opts->logits_out_dev; a.labels_out = labels_out_dev;
     a.samples_out = samples_out_dev; a.err = h->err_dev;
     int kernel = opts->kernel;
     int launches = 1;
@@ -502,7 +517,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         float *tCM = h->tab, *tCA = tCM + nCM, *tVM = tCA + nCA, *tVA = tVM + nVM, *tC2 = tVA + nVA, *tC3 = tC2 + nC2, *tC4 = tC3 + nC3, *tREC = tC4 + nC4;
         const float *w = h->wdev;
         const WrnnPacked &o = h->off;
-        HIP_TRY(h, wrnn_launch_frame_linear(1, mels_dev, (size_t)F * T, 0, 0, w + o.I_t + (size_t)1 * H, H, nullptr, tCM, (size_t)TP * H, TP, F, H, B, T, P, s));
+        HIP_TRY(h, wrnn_launch_frame_linear(1, mels_dev, (size_t)F * mel_T, 0, 0, w + o.I_t + (size_t)1 * H, H, nullptr, tCM, (size_t)TP * H, TP, F, H, B, mel_T, P - mel_off, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames, (size_t)T * R, R, T, w + o.I_t + (size_t)(1 + F) * H, H, w + o.I_b, tCA, (size_t)T1 * H, T1, A, H, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, tCM, (size_t)TP * H, H, TP, w + o.r1_wih_t, 3 * H, nullptr, tVM, (size_t)TP * 3 * H, TP, H, 3 * H, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, tCA, (size_t)T1 * H, H, T1, w + o.r1_wih_t, 3 * H, w + o.r1_bih, tVA, (size_t)T1 * 3 * H, T1, H, 3 * H, B, T, P, s));
@@ -518,10 +533,10 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             if (rpb > WRNN_BATCH_MAX_ROWS) rpb = WRNN_BATCH_MAX_ROWS;
             if (const char *e = getenv("WRNN_BATCH_ROWS")) { rpb = atoi(e); if (rpb < 1) rpb = 1; if (rpb > WRNN_BATCH_MAX_ROWS) rpb = WRNN_BATCH_MAX_ROWS; }   // developer knob
             WrnnBatchArgs ba{};
-            ba.w = w; ba.off = o; ba.d = d; ba.batch_w = h->batch_w; ba.batch_fc3 = h->batch_fc3; ba.wI0 = h->wI0; ba.u1 = h->u1;
+            ba.w = w; ba.off = o; ba.d = d; ba.batch_w = h->batch_w; ba.batch_fc3 = h->batch_fc3; ba.batch_wn = h->batch_wn; ba.wI0 = h->wI0; ba.u1 = h->u1;
             ba.tabREC32 = tREC; ba.rows = h->rows_dev; ba.n_rows = rows; ba.n_teams = h->n_teams; ba.nq = rpb <= 4 ? 1 : 2; ba.rpb = rpb;
             ba.T = T; ba.total_len = a.total_len; ba.steps = steps;
-            ba.noise_mode = a.noise_mode; ba.seed = a.seed; ba.noise1 = a.noise1; ba.noise2 = a.noise2; ba.x_forced = a.x_forced;
+            ba.noise_mode = a.noise_mode; ba.seed = a.seed; ba.noise1 = a.noise1; ba.noise2 = a.noise2; ba.x_forced = a.x_forced; ba.x_init = a.x_init;
             ba.logits_out = a.logits_out; ba.labels_out = a.labels_out; ba.samples_out = a.samples_out;
             ba.mail = h->mail; ba.ctl = h->ctl; ba.err = h->err_dev; ba.prof = h->prof;
             HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
@@ -537,7 +552,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         ta.tabREC = tREC; ta.tabCOND = nullptr; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
         ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = h->n_teams; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
         ta.seg0 = 0; ta.seg_len = steps; ta.state = nullptr;
-        ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced;
+        ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced; ta.x_init = a.x_init;
         ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
         ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;
         {
@@ -587,6 +602,23 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     HIP_TRY(h, hipEventRecord(h->ev[2], s));
     h->timing_valid = true;
     h->last.kernel = kernel; h->last.rows = rows; h->last.steps = steps; h->last.launches = launches;
+    return WRNN_OK;
+}
+
+int wrnn_loss(wrnn_handle *h, const float *y_hat_dev, const void *y_dev, int64_t n_rows, float *loss_out_dev, void *stream) {
+    if (!h || !y_hat_dev || !y_dev || !loss_out_dev || n_rows < 1) return fail(h, WRNN_ERR_INVALID, "wrnn_loss: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nblk = (size_t)(h->d.mode == WRNN_MODE_RAW ? (n_rows + 3) / 4 : (n_rows + 255) / 256);
+    if (nblk + 1 > h->loss_cap) {
+        if (h->loss_partial) (void)hipFree(h->loss_partial);
+        h->loss_partial = nullptr; h->loss_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->loss_partial, (nblk + 1) * sizeof(double)));
+        h->loss_cap = nblk + 1;
+    }
+    int *bad = (int *)(h->loss_partial + nblk);
+    HIP_TRY(h, hipMemsetAsync(bad, 0, sizeof(double), s));
+    HIP_TRY(h, wrnn_launch_loss(h->d.mode, y_hat_dev, y_dev, h->d.NC, (long)n_rows, h->loss_partial, bad, loss_out_dev, s));
     return WRNN_OK;
 }
 

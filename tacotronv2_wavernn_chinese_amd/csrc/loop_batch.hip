@@ -62,6 +62,19 @@ __device__ __forceinline__ u4v ld_pair(__amdgpu_buffer_rsrc_t rs, unsigned byteo
     return __builtin_amdgcn_raw_buffer_load_b128(rs, byteoff, 0, 16 /* sc1 */);
 }
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+// Weights parked in the accumulator half of the register file ("a" constraint = AGPR class for the value's whole life):
+// hipcc allocates at most 256 architectural VGPRs per wave and uses AGPRs only as spill slots, so 320 weights + working set
+// as plain floats overflow into scratch (129 registers, reloaded on the serial chain: measured 13 000 cycles in phase B).
+// Parked explicitly, a weight costs one v_accvgpr_read per use (+ the 2 wait states a VALU-written VGPR needs before an
+// MFMA reads it, which the hazard recognizer cannot add behind inline asm).
+__device__ __forceinline__ void apark(float &dst, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
+__device__ __forceinline__ float aget(const float &a) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1\n\ts_nop 1" : "=v"(v) : "a"(a));
+    return v;
+}
+template <bool AG>
+__device__ __forceinline__ float wget(const float &w) { return AG ? aget(w) : w; }
 
 template <int CTRL>
 __device__ __forceinline__ float dppf(float v) {
@@ -107,10 +120,11 @@ struct Lay {
     static constexpr int R = 4 * NQ;
     static constexpr int VEC = R * 512;            // one activation vector for R rows, B-operand order [rq][S][kp][j][e]
     static constexpr int L_FC3 = 0;                // [4 waves][2 sets][8 S][64 lanes][4 e]: A operands of the fc3 slice
-    static constexpr int L_P = 16384;              // x2, later fc1 outputs
-    static constexpr int L_Q = L_P + VEC;          // x3, later fc2 outputs
-    static constexpr int L_H2 = L_Q + VEC;         // h2' = x3 - x2
-    static constexpr int L_H1 = L_H2 + VEC;        // h1'
+    static constexpr int L_WN = 16384;             // [4 waves][8 S][64 lanes][4 e]: A operands of gate n of W_hh2 (shadow path)
+    static constexpr int L_CST = L_WN + 8192;      // [12][256]: per-thread constants (read once per step, not worth registers)
+    static constexpr int L_P = L_CST + 12 * 256;   // x2, later fc2 outputs
+    static constexpr int L_Q = L_P + VEC;          // x3
+    static constexpr int L_H1 = L_Q + VEC;         // h1', later fc1 outputs        (h2' = x3 - x2 is formed on the fly)
     static constexpr int L_XN = L_H1 + VEC;        // [16] x_{t-1} of every batch row
     static constexpr int L_MISC = L_XN + 16;       // [16]
     static constexpr int L_TOTAL = L_MISC + 16;
@@ -123,37 +137,41 @@ struct Lay {
     static_assert(MAIL <= WRNN_BATCH_MAIL_GRANULES, "mailbox budget");
     static constexpr int NM = R;                   // 16-byte loads per thread per gathered vector (256 threads)
 };
+// slots of L_CST
+constexpr int C_A0 = 0, C_A1 = 1, C_A2 = 2, C_A3 = 3, C_B30 = 4, C_B31 = 5, C_H1R = 6, C_H1Z = 7, C_H1N = 8, C_H2R = 9, C_H2Z = 10, C_H2N = 11;
 constexpr int M_DEAD = 0, M_TEAM = 1, M_RANK = 2;
 
-// gather one published vector (R x 512 granules, mailbox order [rq][wl][S][iu][j][e]) : slice m = (rq, wl) holds the
-// granules wave wl of EVERY workgroup published for row quad rq.  The last slice is polled first (the wave that is
-// dispatched last tends to publish last); the rest is fetched once it is complete.
-template <int NM>
-__device__ __forceinline__ void gather_vec(__amdgpu_buffer_rsrc_t rs, unsigned byteoff, unsigned tag, u4v (&g)[NM], bool &dead,
-                                           unsigned *err, unsigned code) {
+// All-gather of NV published vectors (R x 512 granules each, mailbox order [rq][wl][S][iu][j][e]; slice m = (rq, wl) holds
+// what wave wl of EVERY workgroup published for row quad rq).  Every load of every vector is in flight at once -- one L2
+// round trip when the producers are done, which they normally are: the shadow work of the window sits between the publish
+// and this poll -- and only slices that came back incomplete are read again.
+template <int NM, int NV>
+__device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, const unsigned (&byteoff)[NV], unsigned tag, u4v (&g)[NV][NM],
+                                            bool &dead, unsigned *err, unsigned code) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, byteoff[v] + m * 4096u);
     unsigned spins = 0;
-    g[NM - 1] = ld_pair(rs, byteoff + (NM - 1) * 4096u);
-    while (!dead && !__all(g[NM - 1].y == tag && g[NM - 1].w == tag)) {
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) ok = ok && g[v][m].y == tag && g[v][m].w == tag;
+        if (__all(ok) || dead) break;
         if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
         __builtin_amdgcn_s_sleep(1);
-        g[NM - 1] = ld_pair(rs, byteoff + (NM - 1) * 4096u);
-    }
 #pragma unroll
-    for (int m = 0; m < NM - 1; ++m) g[m] = ld_pair(rs, byteoff + m * 4096u);
-    bool ok = true;
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int m = 0; m < NM - 1; ++m) ok = ok && g[m].y == tag && g[m].w == tag;
-    while (!dead && !__all(ok)) {
-        if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code + 100u); break; }
-        __builtin_amdgcn_s_sleep(1);
-        ok = true;
-#pragma unroll
-        for (int m = 0; m < NM - 1; ++m) { g[m] = ld_pair(rs, byteoff + m * 4096u); ok = ok && g[m].y == tag && g[m].w == tag; }
+            for (int m = 0; m < NM; ++m)
+                if (!__all(g[v][m].y == tag && g[v][m].w == tag)) g[v][m] = ld_pair(rs, byteoff[v] + m * 4096u);
     }
 }
 
 // acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane]
-template <int NQ, int NG>
+template <int NQ, int NG, bool AG>
 __device__ __forceinline__ void mfma_gates(const float *w, const f4 *xv, int lane, f4 (&acc)[NG][NQ]) {
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
@@ -163,13 +181,15 @@ __device__ __forceinline__ void mfma_gates(const float *w, const f4 *xv, int lan
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int gt = 0; gt < NG; ++gt)
+            for (int gt = 0; gt < NG; ++gt) {
+                const float wa = wget<AG>(w[gt * 32 + 4 * S + e]);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[gt][q] = mfma4(w[gt * 32 + 4 * S + e], b[q][e], acc[gt][q]);
+                for (int q = 0; q < NQ; ++q) acc[gt][q] = mfma4(wa, b[q][e], acc[gt][q]);
+            }
     }
 }
 // one weight row set (32 slabs at w[..]); the K sum is split over NP independent accumulator chains
-template <int NQ, int NP>
+template <int NQ, int NP, bool AG>
 __device__ __forceinline__ void mfma_single(const float *w, const f4 *xv, int lane, f4 (&sum)[NQ]) {
     f4 acc[NP][NQ];
 #pragma unroll
@@ -182,9 +202,11 @@ __device__ __forceinline__ void mfma_single(const float *w, const f4 *xv, int la
 #pragma unroll
         for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64 + lane];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) {
+            const float wa = wget<AG>(w[4 * S + e]);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[e % NP][q] = mfma4(w[4 * S + e], b[q][e], acc[e % NP][q]);
+            for (int q = 0; q < NQ; ++q) acc[e % NP][q] = mfma4(wa, b[q][e], acc[e % NP][q]);
+        }
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -260,27 +282,37 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
     //   -> [rq][S = tid>>5][kp = 4 wl' + iu][j][e] = ((rq*8 + S)*16 + 4 wl')*16 + 2*(tid & 31)
     auto pair_dst = [&](int m) { return (((m >> 2) * 8 + (tid >> 5)) * 16 + 4 * (m & 3)) * 16 + 2 * (tid & 31); };
 
-    // ---- resident weights: batch_w [32 WG][4 waves][352][64 lanes] (A-operand images, api.hip):
-    //      W_ih2 r,z,n [0,96) | W_hh1 r,z,n [96,192) | W_hh2 r,z,n [192,288) | fc1 [288,320) | fc2 [320,352)
-    float wv[352];
+    // ---- resident weights: batch_w [32 WG][4 waves][320][64 lanes] (A-operand images, api.hip):
+    //      W_ih2 r,z,n [0,96) -> VGPRs (the serial chain) | W_hh1 r,z,n [96,192) | W_hh2 r,z [192,256) | fc1 [256,288) |
+    //      fc2 [288,320) -> parked in AGPRs.  Gate n of W_hh2 (shadow path: tolerant of LDS latency) and the fc3 slice are
+    //      A-operand images in LDS.
+    float wv[96], wa[224];
     {
-        const float *src = a.batch_w + (((size_t)g * 4 + wl) * 352) * 64 + lane;
+        const float *src = a.batch_w + (((size_t)g * 4 + wl) * 320) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < 352; ++i) wv[i] = src[(size_t)i * 64];
+        for (int i = 0; i < 96; ++i) wv[i] = src[(size_t)i * 64];
+#pragma unroll
+        for (int i = 0; i < 224; ++i) apark(wa[i], src[(size_t)(96 + i) * 64]);
         const float4 *f3 = (const float4 *)(a.batch_fc3 + (size_t)g * 16384);
         float4 *dst = (float4 *)(lds + L::L_FC3);
         for (int i = tid; i < 4096; i += TB_THREADS) dst[i] = f3[i];
+        const float4 *wn = (const float4 *)(a.batch_wn + (size_t)g * 8192);
+        dst = (float4 *)(lds + L::L_WN);
+        for (int i = tid; i < 2048; i += TB_THREADS) dst[i] = wn[i];
         for (int i = tid; i < L::L_TOTAL - L::L_P; i += TB_THREADS) lds[L::L_P + i] = 0.0f;
+        // per-thread constants: W_I[:,0] and u = W_ih1.W_I[:,0] of `unit`, fc3 biases, recurrent biases
+        float *cs = lds + L::L_CST + tid;
+        cs[C_A0 * 256] = a.wI0[unit]; cs[C_A1 * 256] = a.u1[unit]; cs[C_A2 * 256] = a.u1[512 + unit]; cs[C_A3 * 256] = a.u1[1024 + unit];
+        cs[C_B30 * 256] = cls0 < NC ? a.w[a.off.fc3_b + cls0] : 0.0f;
+        cs[C_B31 * 256] = cls0 + 4 < NC ? a.w[a.off.fc3_b + cls0 + 4] : 0.0f;
+        cs[C_H1R * 256] = a.w[a.off.r1_bhh + unit]; cs[C_H1Z * 256] = a.w[a.off.r1_bhh + 512 + unit]; cs[C_H1N * 256] = a.w[a.off.r1_bhh + 1024 + unit];
+        cs[C_H2R * 256] = a.w[a.off.r2_bhh + unit]; cs[C_H2Z * 256] = a.w[a.off.r2_bhh + 512 + unit]; cs[C_H2N * 256] = a.w[a.off.r2_bhh + 1024 + unit];
     }
-    // per-thread constants: W_I[:,0] and u = W_ih1.W_I[:,0] of `unit`, recurrent biases, fc3 biases
-    const float cA0 = a.wI0[unit], cA1 = a.u1[unit], cA2 = a.u1[512 + unit], cA3 = a.u1[1024 + unit];
-    const float b30 = cls0 < NC ? a.w[a.off.fc3_b + cls0] : 0.0f, b31 = cls0 + 4 < NC ? a.w[a.off.fc3_b + cls0 + 4] : 0.0f;
-    const float bh1r = a.w[a.off.r1_bhh + unit], bh1z = a.w[a.off.r1_bhh + 512 + unit], bh1n = a.w[a.off.r1_bhh + 1024 + unit];
-    const float bh2r = a.w[a.off.r2_bhh + unit], bh2z = a.w[a.off.r2_bhh + 512 + unit], bh2n = a.w[a.off.r2_bhh + 1024 + unit];
+    const float *cst = lds + L::L_CST + tid;
     __syncthreads();
 
     const f4 *vP = (const f4 *)(lds + L::L_P), *vQ = (const f4 *)(lds + L::L_Q);
-    const f4 *vH1 = (const f4 *)(lds + L::L_H1), *vH2 = (const f4 *)(lds + L::L_H2);
+    const f4 *vH1 = (const f4 *)(lds + L::L_H1);
 
     bool dead = false;
     unsigned epoch = 0;
@@ -297,14 +329,18 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 
         // h1 = h2 = 0, x = 0 (:194-196)  =>  gh1 = b_hh1, gh2 = b_hh2
         float h1 = 0.0f, h2 = 0.0f, x2own = 0.0f;
-        float gh1r = bh1r, gh1z = bh1z, gh1n = bh1n, gh2r = bh2r, gh2z = bh2z, gh2n = bh2n;
+        float gh1r = cst[C_H1R * 256], gh1z = cst[C_H1Z * 256], gh1n = cst[C_H1N * 256];
+        float gh2r = cst[C_H2R * 256], gh2z = cst[C_H2Z * 256], gh2n = cst[C_H2N * 256];
         float4 cd = make_float4(0.f, 0.f, 0.f, 0.f);      // {cI, v_r, v_z, v_n} of the coming step
         float4 c2 = make_float4(0.f, 0.f, 0.f, 0.f);      // {c2_r, c2_z, c2_n, c3} of the current frame
         float c4 = 0.0f;
         float nz0 = 0.f, nz1 = 0.f, pz0 = 0.f, pz1 = 0.f;  // -log q of classes cls0 / cls0+4: this step | the odd step of the Philox block
         int nfi = (int)(rw.start / HOP), nph = (int)(rw.start - (int64_t)nfi * HOP);   // frame / phase of the step being prepared
         int cst_frame = -1000000, pend_frame = -1;
-        if (tid < R) xn[tid] = 0.0f;
+        if (tid < R) {
+            const int r0 = batch * a.rpb + tid;
+            xn[tid] = (a.x_init && tid < a.rpb && r0 < a.n_rows) ? a.x_init[r0] : 0.0f;
+        }
 
         // conditioning {cI, v_r, v_z, v_n} of step ts for (unit, row): record + 5-tap upsampling (prologue.hip)
         auto prep_cond = [&](int64_t ts) {
@@ -341,15 +377,23 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 nz1 = cls0 + 4 < NC ? -logf(qp[cls0 + 4]) : 0.0f;
             } else if (a.noise_mode == WRNN_NOISE_PHILOX) {
                 // one Philox block = classes (2c, 2c+1) x steps (2s, 2s+1) (device_util.h): evaluated on even steps, the odd
-                // step's draws are kept
+                // step's draws are kept.  Lane l (units 0, 2 of the wave: even classes c, c+4) and lane l+32 (units 1, 3:
+                // classes c+1, c+5) need the same two blocks: the lower lane evaluates block(c), the upper one block(c+4),
+                // and each hands the partner its half with one v_permlane32_swap per step parity.
+                // -log q = -log(-log u): the inner log exactly (q is tiny for u -> 1, where v_log_f32 is not accurate
+                // relative to the result and such a draw tends to win the race), the outer one fast.
                 if ((ts & 1) == 0) {
-                    const Philox4 p0 = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)cls0);
-                    const Philox4 p1 = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)(cls0 + 4));
-                    const bool oddc = (cls0 & 1) != 0;
-                    nz0 = -__logf(-__logf(u01_from_bits(oddc ? p0.y : p0.x)));
-                    nz1 = -__logf(-__logf(u01_from_bits(oddc ? p1.y : p1.x)));
-                    pz0 = -__logf(-__logf(u01_from_bits(oddc ? p0.w : p0.z)));
-                    pz1 = -__logf(-__logf(u01_from_bits(oddc ? p1.w : p1.z)));
+                    const bool upper = lane >= 32;
+                    const Philox4 pb = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)(upper ? cls0 + 4 : cls0));
+                    const float ge = -__logf(-logf(u01_from_bits(pb.x))), go = -__logf(-logf(u01_from_bits(pb.y)));   // even step: class 2c | 2c+1
+                    const float he = -__logf(-logf(u01_from_bits(pb.z))), ho = -__logf(-logf(u01_from_bits(pb.w)));   // odd step
+                    const float mine_e = upper ? go : ge, give_e = upper ? ge : go;
+                    const float mine_o = upper ? ho : he, give_o = upper ? he : ho;
+                    const u2v se = __builtin_amdgcn_permlane32_swap(__float_as_uint(give_e), __float_as_uint(give_e), false, false);
+                    const u2v so = __builtin_amdgcn_permlane32_swap(__float_as_uint(give_o), __float_as_uint(give_o), false, false);
+                    const float recv_e = __uint_as_float(upper ? se.x : se.y), recv_o = __uint_as_float(upper ? so.x : so.y);
+                    nz0 = upper ? recv_e : mine_e; nz1 = upper ? mine_e : recv_e;
+                    pz0 = upper ? recv_o : mine_o; pz1 = upper ? mine_o : recv_o;
                 } else { nz0 = pz0; nz1 = pz1; }
             } else { nz0 = 0.f; nz1 = 0.f; }
         };
@@ -365,10 +409,10 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             {
                 // I + GRU1 for (unit, row) (:208-212); gi = u * x_{t-1} + v[t] (algebra: DESIGN.md 3.2)
                 const float xprev = xn[rb];
-                const float xin = fmaf(cA0, xprev, cd.x);
-                const float rg = sigmoid_fast(fmaf(cA1, xprev, cd.y) + gh1r);
-                const float zg = sigmoid_fast(fmaf(cA2, xprev, cd.z) + gh1z);
-                const float ng = tanh_fast(fmaf(cA3, xprev, cd.w) + rg * gh1n);
+                const float xin = fmaf(cst[C_A0 * 256], xprev, cd.x);
+                const float rg = sigmoid_fast(fmaf(cst[C_A1 * 256], xprev, cd.y) + gh1r);
+                const float zg = sigmoid_fast(fmaf(cst[C_A2 * 256], xprev, cd.z) + gh1z);
+                const float ng = tanh_fast(fmaf(cst[C_A3 * 256], xprev, cd.w) + rg * gh1n);
                 h1 = (1.0f - zg) * ng + zg * h1;
                 x2own = xin + h1;
                 if (primary) {
@@ -379,13 +423,17 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             }
             PB(0);
             {
-                u4v gx[NM];
-                gather_vec<NM>(mrs, (L::G_X2 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 21u);
+                // (both vectors in flight at once would save one L2 round trip, but the 2 x NM x 4 registers of it push the
+                // R = 8 kernel into scratch spills: measured with -Rpass-analysis, 130 vs 17 registers)
+                u4v gx[1][NM];
+                const unsigned offs[1] = {(L::G_X2 + par * L::RG) * 8u + (unsigned)tid * 16u};
+                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 21u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
-                gather_vec<NM>(mrs, (L::G_H1 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 22u);
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                const unsigned offs2[1] = {(L::G_H1 + par * L::RG) * 8u + (unsigned)tid * 16u};
+                gather_vecs<NM, 1>(mrs, offs2, epoch, gx, dead, a.err, 22u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
             PB(1);
             __syncthreads();   // B1
@@ -398,7 +446,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                mfma_gates<NQ, 3>(wv, vP, lane, acc);
+                mfma_gates<NQ, 3, false>(wv, vP, lane, acc);
                 float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -420,24 +468,20 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                mfma_gates<NQ, 3>(wv + 96, vH1, lane, acc);
+                mfma_gates<NQ, 3, true>(wa, vH1, lane, acc);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
-                    if (q == 0 || my_rq == q) { gh1r = fr + bh1r; gh1z = fz + bh1z; gh1n = fn + bh1n; }
+                    if (q == 0 || my_rq == q) { gh1r = fr + cst[C_H1R * 256]; gh1z = fz + cst[C_H1Z * 256]; gh1n = fn + cst[C_H1N * 256]; }
                 }
             }
             PB(4);
             {
-                u4v gx[NM];
-                gather_vec<NM>(mrs, (L::G_X3 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 23u);
+                u4v gx[1][NM];
+                const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u + (unsigned)tid * 16u};
+                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 23u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const float2 x2v = *(const float2 *)(lds + L::L_P + pair_dst(m));
-                    const float x3a = __uint_as_float(gx[m].x), x3b = __uint_as_float(gx[m].z);
-                    *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(x3a, x3b);
-                    *(float2 *)(lds + L::L_H2 + pair_dst(m)) = make_float2(x3a - x2v.x, x3b - x2v.y);   // h2' = x3 - x2
-                }
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
             PB(5);
             __syncthreads();   // B2
@@ -446,7 +490,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 3: phase C (fc1, :217-218) | gh2' = W_hh2 . h2' | gather fc1 outputs =================
             {
                 f4 sum[NQ];
-                mfma_single<NQ, (NQ == 1 ? 4 : 2)>(wv + 288, vQ, lane, sum);
+                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 160, vQ, lane, sum);
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -457,24 +501,44 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             }
             PB(7);
             {
+                // off the serial chain: gh2 of the next step = W_hh2 . h2' + b_hh2, h2' = x3 - x2 formed on the fly from the two
+                // gathered vectors (the same subtraction team2 does when x3 arrives); gate n's weights come from LDS
                 f4 acc[3][NQ];
 #pragma unroll
                 for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                mfma_gates<NQ, 3>(wv + 192, vH2, lane, acc);
+                const f4 *wnl = (const f4 *)(lds + L::L_WN) + (size_t)wl * 8 * 64 + lane;
+#pragma unroll
+                for (int S = 0; S < 8; ++S) {
+                    f4 b[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64 + lane] - vP[(q * 8 + S) * 64 + lane];
+                    const f4 wn = wnl[S * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float wr = aget(wa[96 + 4 * S + e]), wz = aget(wa[128 + 4 * S + e]);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            acc[0][q] = mfma4(wr, b[q][e], acc[0][q]);
+                            acc[1][q] = mfma4(wz, b[q][e], acc[1][q]);
+                            acc[2][q] = mfma4(wn[e], b[q][e], acc[2][q]);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
-                    if (q == 0 || my_rq == q) { gh2r = fr + bh2r; gh2z = fz + bh2z; gh2n = fn + bh2n; }
+                    if (q == 0 || my_rq == q) { gh2r = fr + cst[C_H2R * 256]; gh2z = fz + cst[C_H2Z * 256]; gh2n = fn + cst[C_H2N * 256]; }
                 }
             }
             PB(8);
             {
-                u4v gx[NM];
-                gather_vec<NM>(mrs, (L::G_F1 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 24u);
+                u4v gx[1][NM];
+                const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u + (unsigned)tid * 16u};
+                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 24u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
             PB(9);
             __syncthreads();   // B3
@@ -482,7 +546,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 4: phase D (fc2, :220-221) | noise of this step, conditioning of the next | gather fc2 =================
             {
                 f4 sum[NQ];
-                mfma_single<NQ, (NQ == 1 ? 4 : 2)>(wv + 320, vP, lane, sum);
+                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 192, vH1, lane, sum);
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -495,10 +559,11 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             prep_noise(t);
             if (t + 1 < a.steps) prep_cond(t + 1);
             {
-                u4v gx[NM];
-                gather_vec<NM>(mrs, (L::G_F2 + par * L::RG) * 8u + (unsigned)tid * 16u, epoch, gx, dead, a.err, 25u);
+                u4v gx[1][NM];
+                const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u + (unsigned)tid * 16u};
+                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 25u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[m].x), __uint_as_float(gx[m].z));
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
             PB(11);
             __syncthreads();   // B4
@@ -520,7 +585,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     for (int S = 0; S < 8; ++S) {
                         f4 b[NQ];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64 + lane];
+                        for (int q = 0; q < NQ; ++q) b[q] = vP[(q * 8 + S) * 64 + lane];
                         const f4 wa = w3[S * 64], wb = w3[(8 + S) * 64];
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -538,7 +603,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                         const float f0 = fold_kp(s0), f1 = fold_kp(s1);
                         if (q == 0 || my_rq == q) { lg0 = f0; lg1 = f1; }
                     }
-                    lg0 += b30; lg1 += b31;
+                    lg0 += cst[C_B30 * 256]; lg1 += cst[C_B31 * 256];
                     if (a.logits_out && primary && row_ok) {
                         float *lo = a.logits_out + ((size_t)t * a.n_rows + row) * NC;
                         if (cls0 < NC) lo[cls0] = lg0;
@@ -580,23 +645,36 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 }
             }
             PB(12);
-            // ---- exchange 5: wave w finishes batch rows w, w + 4 ----
+            // ---- exchange 5: wave w finishes batch rows w, w + 4 (the candidates of both rows are fetched together) ----
+            u4v gqa[NQ];
+            if (MODE == WRNN_MODE_RAW) {
+                const unsigned tg = epoch & 0x3fffffu;
 #pragma unroll
-            for (int brow = wl; brow < R; brow += 4) {
+                for (int i = 0; i < NQ; ++i) gqa[i] = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u + (unsigned)lane * 16u);
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) ok = ok && (gqa[i].y >> 10) == tg && (gqa[i].w >> 10) == tg;
+                    if (__all(ok) || dead) break;
+                    if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 26u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+                        if (!__all((gqa[i].y >> 10) == tg && (gqa[i].w >> 10) == tg))
+                            gqa[i] = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u + (unsigned)lane * 16u);
+                }
+            }
+#pragma unroll
+            for (int bi = 0; bi < NQ; ++bi) {
+                const int brow = wl + 4 * bi;
                 const int rrow_raw = batch * a.rpb + brow;
                 const bool rok = brow < a.rpb && rrow_raw < a.n_rows;
                 const int rrow = rok ? rrow_raw : a.n_rows - 1;
                 float x_new;
                 int lab;
                 if (MODE == WRNN_MODE_RAW) {
-                    u4v gq = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)brow * 128u) * 8u + (unsigned)lane * 16u);
-                    unsigned spins = 0;
-                    const unsigned tg = epoch & 0x3fffffu;
-                    while (!dead && !__all((gq.y >> 10) == tg && (gq.w >> 10) == tg)) {
-                        if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 26u); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        gq = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)brow * 128u) * 8u + (unsigned)lane * 16u);
-                    }
+                    const u4v gq = gqa[bi];
                     const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
                     const bool pb = vb > va;   // equal scores: the lower slot = the lower class range wins
                     const float best = pb ? vb : va;

@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         // first segment: h1 = h2 = 0, x = 0  (:194-196)  => gh1 = b_hh1, gh2 = b_hh2; later segments: the state the
         // previous launch left in `st`
         float h1_j = resume ? st[tid] : 0.0f;
-        float xfeed = resume ? st[4096] : 0.0f;   // x_{t-1} (:196)
+        float xfeed = resume ? st[4096] : (a.x_init ? a.x_init[row] : 0.0f);   // x_{t-1} (:196)
         xb[XB_H2 * 512 + pj] = resume ? st[512 + tid] : 0.0f;
         for (int i = tid; i < 1536; i += T2_THREADS) gh1s[i] = resume ? st[1024 + i] : a.w[a.off.r1_bhh + i];
         if (tid == 0) misc_f[M_XF] = xfeed;
@@ -380,10 +380,12 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                     // Philox evaluation per lane every 32 steps; the lane that owns step ts hands its draw over.
                     if ((ts & 31) == 0) {
                         const Philox4 pz = wrnn_raw_block(a.seed, (uint64_t)ts + 2u * (unsigned)q, (uint32_t)row, (uint32_t)c3row0);
-                        nzE0 = -__logf(-__logf(u01_from_bits(pz.x)));
-                        nzE1 = -__logf(-__logf(u01_from_bits(pz.y)));
-                        nzn0 = -__logf(-__logf(u01_from_bits(pz.z)));
-                        nzn1 = -__logf(-__logf(u01_from_bits(pz.w)));
+                        // -log q = -log(-log u): the inner log exactly (q is tiny for u -> 1, where v_log_f32 is not accurate
+                        // relative to the result -- and such a draw tends to win the race), the outer one fast
+                        nzE0 = -__logf(-logf(u01_from_bits(pz.x)));
+                        nzE1 = -__logf(-logf(u01_from_bits(pz.y)));
+                        nzn0 = -__logf(-logf(u01_from_bits(pz.z)));
+                        nzn1 = -__logf(-logf(u01_from_bits(pz.w)));
                     }
                     if (q == (int)((ts >> 1) & 15)) {
                         const bool odd = (ts & 1) != 0;

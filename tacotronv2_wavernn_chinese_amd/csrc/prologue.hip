@@ -22,12 +22,11 @@
 #include "wrnn_internal.h"
 
 #define RESNET_FT 8      // frames per workgroup
-#define RESNET_THREADS 128
 
-// grid (ceil(T/FT), B), block 128 (thread c = output channel c; C == R == 128)
-__global__ void __launch_bounds__(RESNET_THREADS)
-resnet_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const float *__restrict__ mels, int T,
-              float *__restrict__ aux_frames) {
+// grid (ceil(T/FT), B), block = max(C, R) rounded up to a wave (thread c = output channel c; 128 for the reference hparams)
+__global__ void __launch_bounds__(1024)
+resnet_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const float *__restrict__ mels, int T, int mel_T,
+              int mel_off, float *__restrict__ aux_frames) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = d.F, C = d.C, R = d.R, P = d.P, KS = d.KS;
     const int FT = RESNET_FT;
@@ -36,11 +35,12 @@ resnet_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const flo
     float *xb = xa + FT * C;               // [FT][C]
     const int b = blockIdx.y, t0 = blockIdx.x * FT, c = threadIdx.x;
 
-    // pad_tensor(..., side='both'): zeros outside [0, T)   (:281-291)
+    // pad_tensor(..., side='both'): zeros outside [0, T)   (:281-291).  A caller that hands over mels already padded
+    // by `pad` frames each side (WaveRNN.forward, :143) sets mel_T = T + 2 pad, mel_off = pad: every frame is read.
     for (int i = threadIdx.x; i < (FT + KS - 1) * F; i += blockDim.x) {
         const int fr = i / F, f = i - fr * F;
-        const int t = t0 + fr - P;
-        xp[i] = (t >= 0 && t < T) ? mels[((size_t)b * F + f) * T + t] : 0.0f;
+        const int t = t0 + fr - P + mel_off;
+        xp[i] = (t >= 0 && t < mel_T) ? mels[((size_t)b * F + f) * mel_T + t] : 0.0f;
     }
     __syncthreads();
 
@@ -117,14 +117,14 @@ resnet_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const flo
     }
 }
 
-hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, float *aux_frames,
+hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, int mel_T, int mel_off, float *aux_frames,
                               hipStream_t s) {
     (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     const WrnnDims &d = h->d;
     dim3 grid((T + RESNET_FT - 1) / RESNET_FT, B);
     size_t lds = ((size_t)(RESNET_FT + d.KS - 1) * d.F + 2 * (size_t)RESNET_FT * d.C) * sizeof(float);
-    hipLaunchKernelGGL(resnet_kernel, grid, dim3(RESNET_THREADS), lds, s, h->wdev, h->off, d, mels, T,
-                       aux_frames);
+    const int nthr = (((d.C > d.R ? d.C : d.R) + 63) / 64) * 64;
+    hipLaunchKernelGGL(resnet_kernel, grid, dim3(nthr), lds, s, h->wdev, h->off, d, mels, T, mel_T, mel_off, aux_frames);
     return hipGetLastError();
 }
 
@@ -134,7 +134,7 @@ hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, in
 // grid (ceil(T*HOP / 64), B), block 256: 64 positions x (F + R = 208 channels) per block, channel fastest.
 __global__ void __launch_bounds__(256)
 materialize_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, const float *__restrict__ mels,
-                   const float *__restrict__ aux_frames, int T, float *__restrict__ up,
+                   const float *__restrict__ aux_frames, int T, int mel_T, int mel_off, float *__restrict__ up,
                    float *__restrict__ aux_up) {
     const int F = d.F, R = d.R, HOP = d.HOP, ND = d.ND, P = d.P;
     const int b = blockIdx.y;
@@ -151,8 +151,8 @@ materialize_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, cons
             if (!up) continue;
             float acc = 0.0f;
             for (int k = 0; k < ND; ++k) {
-                const int fr = i + k - P;  // melpad[i + k] = mel[i + k - pad], zero outside
-                const float mv = (fr >= 0 && fr < T) ? mels[((size_t)b * F + c) * T + fr] : 0.0f;
+                const int fr = i + k - P + mel_off;  // melpad[i + k] = mel[i + k - pad], zero outside
+                const float mv = (fr >= 0 && fr < mel_T) ? mels[((size_t)b * F + c) * mel_T + fr] : 0.0f;
                 acc = fmaf(ktab[r * ND + k], mv, acc);
             }
             up[((size_t)b * L + t) * F + c] = acc;
@@ -165,12 +165,12 @@ materialize_kernel(const float *__restrict__ w, WrnnPacked off, WrnnDims d, cons
 }
 
 hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, const float *aux_frames, int B,
-                                   int T, float *up, float *aux_up, hipStream_t s) {
+                                   int T, int mel_T, int mel_off, float *up, float *aux_up, hipStream_t s) {
     (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     const WrnnDims &d = h->d;
     const long L = (long)T * d.HOP;
     dim3 grid((unsigned)((L + 63) / 64), B);
-    hipLaunchKernelGGL(materialize_kernel, grid, dim3(256), 0, s, h->wdev, h->off, d, mels, aux_frames, T, up,
+    hipLaunchKernelGGL(materialize_kernel, grid, dim3(256), 0, s, h->wdev, h->off, d, mels, aux_frames, T, mel_T, mel_off, up,
                        aux_up);
     return hipGetLastError();
 }

@@ -78,7 +78,8 @@ struct wrnn_handle {
     unsigned *err_dev = nullptr;  // device error word (bounded spins)
     // team kernel state
     float *team_w = nullptr, *team_fc3 = nullptr, *wI0 = nullptr, *u1 = nullptr;
-    float *batch_w = nullptr, *batch_fc3 = nullptr;   // batch kernel images of the same weights
+    float *batch_w = nullptr, *batch_fc3 = nullptr, *batch_wn = nullptr;   // batch kernel images of the same weights
+    bool team_dims = false;       // the constructor dims are the reference hparams the team kernels are built for
     bool team_ok = false;         // the 32-workgroup team kernels can be co-resident on this device (checked at create)
     std::string team_why;         // why not, when team_ok is false
     float *tab = nullptr;         // CM|CA|VM|VA|C2|C3|C4 for the current batch
@@ -94,6 +95,8 @@ struct wrnn_handle {
     int n_teams = 8;              // XCDs (32-CU teams) of this device
     unsigned long long *prof = nullptr;   // set when WRNN_TEAM_PROF=1 in the environment
     double prof_div = 0;
+    double *loss_partial = nullptr;   // per-block partial sums of wrnn_loss
+    size_t loss_cap = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
     wrnn_timing last{};
@@ -105,7 +108,8 @@ struct WrnnLoopArgs {
     const float *w;           // packed weights
     WrnnPacked off;
     WrnnDims d;
-    const float *mels;        // (B, F, T)
+    const float *mels;        // (B, F, mel_T)
+    int32_t mel_T, mel_off;   // frames per mel row, index of frame 0 (see wrnn_launch_resnet)
     const float *aux_frames;  // (B, T, R)
     const WrnnRow *rows;
     int32_t n_rows;
@@ -117,6 +121,7 @@ struct WrnnLoopArgs {
     const float *noise1;      // RAW (L, rows, NC) | MOL (L, rows, 10)
     const float *noise2;      // MOL (L, rows)
     const float *x_forced;    // (L, rows) or null
+    const float *x_init;      // (rows) value fed to step 0 instead of 0, or null (teacher-forced forward())
     float *logits_out;        // (L, rows, NC) or null
     int32_t *labels_out;      // (rows, L) or null
     float *samples_out;       // (rows, L)
@@ -163,6 +168,7 @@ struct WrnnTeamArgs {
     const float *noise1;
     const float *noise2;
     const float *x_forced;
+    const float *x_init;
     float *logits_out;
     int32_t *labels_out;
     float *samples_out;
@@ -182,8 +188,9 @@ struct WrnnBatchArgs {
     const float *w;           // packed weights (biases, ktab)
     WrnnPacked off;
     WrnnDims d;
-    const float *batch_w;     // [32 WGs][4 waves][352][64 lanes] MFMA A-operand images of the register-resident weights
+    const float *batch_w;     // [32 WGs][4 waves][320][64 lanes] MFMA A-operand images of the register-resident weights
     const float *batch_fc3;   // [32 WGs][4 waves][2 sets][8][64 lanes][4] A-operand image of the fc3 slice (LDS)
+    const float *batch_wn;    // [32 WGs][4 waves][8][64 lanes][4] A-operand image of gate n of W_hh2 (LDS)
     const float *wI0;         // [H]   W_I[:,0]
     const float *u1;          // [3H]  W_ih1 . W_I[:,0]
     const float *tabREC32;    // (B, T+1, H, 32): the 24 phase-A record floats (pack_records_kernel) | c2 r,z,n | c3 | c4 | pad
@@ -200,6 +207,7 @@ struct WrnnBatchArgs {
     const float *noise1;
     const float *noise2;
     const float *x_forced;
+    const float *x_init;
     float *logits_out;
     int32_t *labels_out;
     float *samples_out;
@@ -210,14 +218,19 @@ struct WrnnBatchArgs {
 };
 
 // kernels / launchers (defined in the .hip files)
-hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, float *aux_frames,
+// mel_T = frames per row of `mels`, mel_off = index of frame 0 in it: (T, 0) for generate()'s unpadded mels (zero
+// padding applied on the fly, :183), (T + 2 pad, pad) for mels already padded like WaveRNN.forward receives them (:143)
+hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, int T, int mel_T, int mel_off, float *aux_frames,
                               hipStream_t s);
 hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, const float *aux_frames, int B,
-                                   int T, float *up, float *aux_up, hipStream_t s);
+                                   int T, int mel_T, int mel_off, float *up, float *aux_up, hipStream_t s);
 hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
+size_t wrnn_simple_lds_bytes(const WrnnDims &d);
 hipError_t wrnn_launch_loop_batch(const WrnnBatchArgs &a, hipStream_t s);
 hipError_t wrnn_batch_occupancy(int nq, int *blocks_per_cu, size_t *lds_bytes);
 hipError_t wrnn_team2_occupancy(int *blocks_per_cu, size_t *lds_bytes);
+hipError_t wrnn_launch_loss(int mode, const float *y_hat, const void *y, int NC, long n_rows, double *partial, int *bad, float *out,
+                            hipStream_t s);
 hipError_t wrnn_launch_rows(WrnnRow *rows, int n_rows, int batched, long stride, hipStream_t s);
 hipError_t wrnn_launch_pack_records32(const float *CM, const float *CA, const float *VM, const float *VA, const float *C2,
                                       const float *C3, const float *C4, float *rec, int B, int T, int P, hipStream_t s);

@@ -14,7 +14,8 @@ The class is an ``nn.Module`` purely as a parameter container: sub-module
 names and construction order follow the reference so that ``state_dict()``
 keys, ``load_state_dict`` and the default initialisation under a given
 ``torch.manual_seed`` are interchangeable with it.  ``forward`` (teacher-forced
-training pass, :131-167) is out of scope.
+pass, :131-167) runs the same loop kernels with the fed-back value forced;
+the losses of the training script live in ``losses.py``.
 """
 from __future__ import annotations
 
@@ -151,12 +152,34 @@ class WaveRNN(nn.Module):
         return self._native
 
     def forward(self, x, mels):
-        raise NotImplementedError('teacher-forced training forward (fatchord_version.py:131-167) is out of scope '
-                                  'of the MI355X mel->wav path')
+        """Teacher-forced pass of the reference (``forward``, :131-167) on the hot path's own kernels: ``x`` (B, L) is the
+        input sample sequence, ``mels`` (B, n_mels, T + 2*pad) the mel window already padded with ``pad`` context frames on
+        both sides (what the training collate hands over, :143), L = T * hop.  Returns the fc3 outputs (B, L, n_classes) --
+        logits (RAW) / mixture parameters (MOL) -- as a float32 tensor on the model's device.  Inference only (no autograd
+        graph): it is the loop of ``generate`` with the fed-back value forced to ``x`` and the sampler's result ignored.
+        Increments ``step`` like the reference (:139).
+        """
+        x_t = torch.as_tensor(x, dtype=torch.float32)
+        mels_t = torch.as_tensor(mels)
+        if mels_t.dim() != 3 or x_t.dim() != 2:
+            raise ValueError(f'expected x (B, L) and mels (B, n_mels, T + 2*pad), got {tuple(x_t.shape)}, {tuple(mels_t.shape)}')
+        T = mels_t.size(-1) - 2 * self.pad
+        if T < 1 or x_t.shape != (mels_t.size(0), T * self.hop_length):
+            raise ValueError(f'x must be (B, {max(T, 0) * self.hop_length}) for mels {tuple(mels_t.shape)} (pad {self.pad}, hop {self.hop_length})')
+        self.step += 1
+        xs = x_t.detach().cpu().numpy()
+        x_forced = np.zeros((xs.shape[1], xs.shape[0]), np.float32)
+        x_forced[:-1] = xs[:, 1:].T                      # the value fed to step t + 1 is x[:, t + 1]
+        kw = dict(noise_mode=_cabi.NOISE_ARGMAX) if self.mode == 'RAW' else \
+            dict(noise_mode=_cabi.NOISE_PHILOX, seed=0)  # the drawn samples are discarded
+        res = self.generate_raw(mels_t, False, 11000, 550, x_forced=x_forced, x_init=xs[:, 0], want_logits=True,
+                                mels_padded=True, **kw)
+        return res['logits'].permute(1, 0, 2).contiguous()
 
     # ---------------------------------------------------------------- generate
     def generate_raw(self, mels, batched, target, overlap, *, noise_mode=_cabi.NOISE_PHILOX, seed=0,
-                     noise1=None, noise2=None, x_forced=None, want_logits=False, kernel=None):
+                     noise1=None, noise2=None, x_forced=None, want_logits=False, kernel=None, x_init=None,
+                     mels_padded=False):
         """Device part of generate() (:183-241).  Returns dict(samples (rows, L) float32 cuda tensor,
         labels (rows, L) int32 cuda tensor, logits or None, rows, steps).
 
@@ -170,6 +193,8 @@ class WaveRNN(nn.Module):
             if mels_t.dim() != 3:
                 raise ValueError(f'expected mels shaped (B, n_mels, T), got {tuple(mels_t.shape)}')
             B, F, T = mels_t.shape
+            if mels_padded:
+                T -= 2 * self.pad                        # forward()'s layout: `pad` context frames on both sides
             if F != self.feat_dims:   # the reference dies in conv_in with a channel mismatch (:43); a (T, n_mels) array lands here too
                 raise ValueError(f'expected mels shaped (B, {self.feat_dims}, T), got {tuple(mels_t.shape)}')
             rows, steps = nat.plan(B, T, batched, target, overlap)
@@ -189,13 +214,14 @@ class WaveRNN(nn.Module):
             n1 = to_dev(noise1, (steps, rows, nmix))
             n2 = to_dev(noise2, (steps, rows))
             xf = to_dev(x_forced, (steps, rows))
+            xi = to_dev(x_init, (rows,))
             logits = torch.empty((steps, rows, self.n_classes), dtype=torch.float32, device=dev) if want_logits else None
             stream = torch.cuda.current_stream(dev).cuda_stream
             nat.generate(mels_t.data_ptr(), B, T, batched, target, overlap,
                          labels_ptr=labels.data_ptr(), samples_ptr=samples.data_ptr(), stream=stream,
                          noise_mode=noise_mode, seed=int(seed), noise1_ptr=n1, noise2_ptr=n2, x_forced_ptr=xf,
                          logits_ptr=logits.data_ptr() if logits is not None else 0,
-                         kernel=self.kernel if kernel is None else kernel)
+                         kernel=self.kernel if kernel is None else kernel, x_init_ptr=xi, mels_padded=mels_padded)
             self.last_timing = nat.last_timing()  # synchronises; surfaces device-side errors
             del keep
         return dict(samples=samples, labels=labels, logits=logits, rows=rows, steps=steps)

@@ -62,3 +62,20 @@ def test_epilogue_rejects_short_clips():
     # the reference crashes for T < 21 (broadcast error at fatchord_version.py:258)
     with pytest.raises(ValueError):
         orc.epilogue(np.zeros((1, 20 * 275), np.float32), 1024, True, False, 11000, 550, 19 * 275, 275)
+
+
+@pytest.mark.parametrize('name', ['raw_peaky_b1_t401', 'raw_peaky_b8_t60'])
+def test_baseline_size_goldens_pin_the_fast_oracle(name):
+    """The BASELINE-size fixtures (configs[1]'s 110 275-step clip; B=8, T=60) were minted from the unmodified reference
+    (oracle/make_golden.py long): the OpenMP/AVX2 build of the restatement -- the checker of the GPU tests at those
+    sizes -- reproduces the reference's labels bit for bit over the whole free-running sequence, and its wav."""
+    from tests.golden_util import LONG_CASES
+    assert name in LONG_CASES
+    fx = load_case(name)
+    om = orc.OracleModel(fx['state_dict'], fast=True)
+    cm, ca = om.conditioning(fx['mels'])
+    r = om.loop(cm, ca, orc.NOISE_EXPO, fx['noise']['expo'])
+    np.testing.assert_array_equal(r['labels'], fx['labels'].astype(np.int32))
+    if fx['wav'].size:
+        wav = orc.epilogue(r['samples'].T, 1024, True, False, 11000, 550, (int(fx['T']) - 1) * 275, 275)
+        np.testing.assert_array_equal(wav.astype(np.float32), fx['wav'])
