@@ -391,7 +391,7 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
     if (!h->mail) {
         HIP_TRY(h, hipMalloc(&h->mail, (size_t)8 * WRNN_MAIL_GRANULES_MAX * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->ctl, 128));
-        if (getenv("WRNN_TEAM_PROF")) { HIP_TRY(h, hipMalloc(&h->prof, 8 * 17 * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->prof, 0, 8 * 17 * sizeof(unsigned long long))); }
+        if (getenv("WRNN_TEAM_PROF")) { HIP_TRY(h, hipMalloc(&h->prof, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long))); }
     }
     if (h->wdev) { (void)hipFree(h->wdev); h->wdev = nullptr; }
     HIP_TRY(h, hipMalloc(&h->wdev, o.total * sizeof(float)));
@@ -541,7 +541,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             ba.mail = h->mail; ba.ctl = h->ctl; ba.err = h->err_dev; ba.prof = h->prof;
             HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
             HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
-            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * 17 * sizeof(unsigned long long), s));
+            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long), s));
             HIP_TRY(h, hipEventRecord(h->ev[1], s));  // tables and records are prologue work
             HIP_TRY(h, wrnn_launch_loop_batch(ba, s));
             h->prof_div = (double)steps * ((((rows + rpb - 1) / rpb) + h->n_teams - 1) / h->n_teams);
@@ -582,7 +582,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
                 h->team_state_cap = nST;
             }
             HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work; the stream chunks are timed with the loop
-            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * 17 * sizeof(unsigned long long), s));
+            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long), s));
             ta.team_w = h->team_w; ta.tabCOND = h->cond; ta.state = h->team_state;
             h->prof_div = (double)steps * ((rows + h->n_teams - 1) / h->n_teams);
             for (int64_t t0 = 0; t0 < steps; t0 += seg) {
@@ -633,13 +633,13 @@ int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out) {
     HIP_TRY(h, hipMemcpy(&errw, h->err_dev, sizeof(errw), hipMemcpyDeviceToHost));
     if (out) *out = h->last;
     if (h->prof && (h->last.kernel == WRNN_KERNEL_TEAM2 || h->last.kernel == WRNN_KERNEL_BATCH)) {
-        unsigned long long pr[8 * 17];
+        unsigned long long pr[8 * WRNN_PROF_SLOTS];
         HIP_TRY(h, hipMemcpy(pr, h->prof, sizeof(pr), hipMemcpyDeviceToHost));
         const double n = h->prof_div > 0 ? h->prof_div : 1.0;   // steps x rows (or batches) team 0 ran
         for (int wv = 0; wv < 8; ++wv) {
             fprintf(stderr, "[wrnn prof] %s %d cycles/step:", h->last.kernel == WRNN_KERNEL_TEAM2 ? "team2 wg0 wave" : "batch wg0 wave", wv);
             double tot = 0;
-            for (int i = 0; i < 17; ++i) { fprintf(stderr, " %.0f", pr[wv * 17 + i] / n); tot += pr[wv * 17 + i] / n; }
+            for (int i = 0; i < WRNN_PROF_SLOTS; ++i) { fprintf(stderr, " %.0f", pr[wv * WRNN_PROF_SLOTS + i] / n); tot += pr[wv * WRNN_PROF_SLOTS + i] / n; }
             fprintf(stderr, " | total %.0f\n", tot);
         }
     }

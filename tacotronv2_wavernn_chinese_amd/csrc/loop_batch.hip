@@ -218,10 +218,14 @@ __device__ __forceinline__ void mfma_single(const float *w, const f4 *xv, int la
 
 }  // namespace
 
+// phase-cycle instrumentation (WRNN_TEAM_PROF=1): the scheduling barriers keep the (side-effect free) MFMAs and VALU work of a
+// phase on its own side of the time stamp
 #define PB(i)                                                    \
     do {                                                         \
         if (PROF) {                                              \
+            __builtin_amdgcn_sched_barrier(0);                   \
             const u64 now_ = __builtin_readcyclecounter();       \
+            __builtin_amdgcn_sched_barrier(0);                   \
             prof_acc[i] += now_ - prof_last;                     \
             prof_last = now_;                                    \
         }                                                        \
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 
     bool dead = false;
     unsigned epoch = 0;
-    u64 prof_acc[16] = {0};
+    u64 prof_acc[WRNN_PROF_SLOTS] = {0};
     u64 prof_last = 0;
 
     for (int batch = team; batch < n_batches; batch += a.n_teams) {
@@ -421,13 +425,14 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 }
                 frame_consts();   // constants of this step's frame (needed from phase B on)
             }
-            PB(0);
+            PB(0);   // phase A + publish
             {
                 // (both vectors in flight at once would save one L2 round trip, but the 2 x NM x 4 registers of it push the
                 // R = 8 kernel into scratch spills: measured with -Rpass-analysis, 130 vs 17 registers)
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_X2 + par * L::RG) * 8u + (unsigned)tid * 16u};
                 gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 21u);
+                PB(1);   // x2 arrived
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
                 const unsigned offs2[1] = {(L::G_H1 + par * L::RG) * 8u + (unsigned)tid * 16u};
@@ -435,9 +440,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
-            PB(1);
+            PB(2);   // h1' gathered, both written
             __syncthreads();   // B1
-            PB(2);
+            PB(3);
 
             // ================= window 2: phase B (GRU2, :213-216) | gh1' = W_hh1 . h1' | gather x3 =================
             {
@@ -447,12 +452,14 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 mfma_gates<NQ, 3, false>(wv, vP, lane, acc);
+                PB(4);   // phase B MFMAs issued
                 float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
                     if (q == 0 || my_rq == q) { tr = fr; tz = fz; tn = fn; }
                 }
+                PB(5);   // folded
                 const float rg = sigmoid_fast((tr + c2.x) + gh2r);
                 const float zg = sigmoid_fast((tz + c2.y) + gh2z);
                 const float ng = tanh_fast((tn + c2.z) + rg * gh2n);
@@ -460,7 +467,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 const float x3 = x2own + h2;
                 if (primary) st_granule(mail, L::G_X3 + par * L::RG + mb_own, epoch, __float_as_uint(x3));
             }
-            PB(3);
+            PB(6);   // gates + publish x3
             {
                 // off the serial chain, under the x3 exchange: gh1 of the next step
                 f4 acc[3][NQ];
@@ -469,13 +476,14 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 mfma_gates<NQ, 3, true>(wa, vH1, lane, acc);
+                PB(7);   // W_hh1 MFMAs issued
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
                     if (q == 0 || my_rq == q) { gh1r = fr + cst[C_H1R * 256]; gh1z = fz + cst[C_H1Z * 256]; gh1n = fn + cst[C_H1N * 256]; }
                 }
             }
-            PB(4);
+            PB(8);   // W_hh1 folded
             {
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u + (unsigned)tid * 16u};
@@ -483,9 +491,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
-            PB(5);
+            PB(9);   // x3 gathered
             __syncthreads();   // B2
-            PB(6);
+            PB(10);
 
             // ================= window 3: phase C (fc1, :217-218) | gh2' = W_hh2 . h2' | gather fc1 outputs =================
             {
@@ -499,7 +507,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 }
                 if (primary) st_granule(mail, L::G_F1 + par * L::RG + mb_own, epoch, __float_as_uint(fmaxf(s + c2.w, 0.0f)));
             }
-            PB(7);
+            PB(11);  // fc1 + publish
             {
                 // off the serial chain: gh2 of the next step = W_hh2 . h2' + b_hh2, h2' = x3 - x2 formed on the fly from the two
                 // gathered vectors (the same subtraction team2 does when x3 arrives); gate n's weights come from LDS
@@ -532,7 +540,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     if (q == 0 || my_rq == q) { gh2r = fr + cst[C_H2R * 256]; gh2z = fz + cst[C_H2Z * 256]; gh2n = fn + cst[C_H2N * 256]; }
                 }
             }
-            PB(8);
+            PB(12);  // W_hh2
             {
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u + (unsigned)tid * 16u};
@@ -540,8 +548,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
-            PB(9);
+            PB(13);  // f1 gathered
             __syncthreads();   // B3
+            PB(14);
 
             // ================= window 4: phase D (fc2, :220-221) | noise of this step, conditioning of the next | gather fc2 =================
             {
@@ -555,9 +564,11 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 }
                 if (primary) st_granule(mail, L::G_F2 + par * L::RG + mb_own, epoch, __float_as_uint(fmaxf(s + c4, 0.0f)));
             }
-            PB(10);
+            PB(15);  // fc2 + publish
             prep_noise(t);
+            PB(16);  // noise
             if (t + 1 < a.steps) prep_cond(t + 1);
+            PB(17);  // conditioning of the next step
             {
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u + (unsigned)tid * 16u};
@@ -565,8 +576,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
-            PB(11);
+            PB(18);  // f2 gathered
             __syncthreads();   // B4
+            PB(19);
 
             // ================= window 5: phase E (fc3 :223 + sampler :225-237) | race =================
             {
@@ -644,7 +656,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     }
                 }
             }
-            PB(12);
+            PB(20);  // fc3 + race in the wave + publish
             // ---- exchange 5: wave w finishes batch rows w, w + 4 (the candidates of both rows are fetched together) ----
             u4v gqa[NQ];
             if (MODE == WRNN_MODE_RAW) {
@@ -665,6 +677,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                             gqa[i] = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u + (unsigned)lane * 16u);
                 }
             }
+            PB(21);  // race candidates arrived
 #pragma unroll
             for (int bi = 0; bi < NQ; ++bi) {
                 const int brow = wl + 4 * bi;
@@ -726,9 +739,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     }
                 }
             }
-            PB(13);
+            PB(22);  // winners reduced
             __syncthreads();   // B5
-            PB(14);
+            PB(23);
             if ((t & 63) == 63) {   // bounded-spin bail-out, checked workgroup-wide every 64 steps
                 if (dead && lane == 0) misc_i[M_DEAD] = 1;
                 __syncthreads();
@@ -738,7 +751,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
         __syncthreads();
     }
     if (PROF && a.prof && lane == 0 && g == 0 && team == 0) {
-        for (int i = 0; i < 16; ++i) a.prof[wl * 17 + i] += prof_acc[i];
+        for (int i = 0; i < WRNN_PROF_SLOTS; ++i) a.prof[wl * WRNN_PROF_SLOTS + i] += prof_acc[i];
     }
 }
 

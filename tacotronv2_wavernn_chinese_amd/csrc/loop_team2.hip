@@ -118,8 +118,12 @@ __device__ __forceinline__ float wave_max(float v) {   // max over 64 lanes, val
     return v;
 }
 
-// activation vectors in LDS: element j -> plane p=(j>>2)&7, slot q=j>>5 (8 conflict-free ds_read_b128 per lane)
-__device__ __forceinline__ int perm(int j) { return ((j >> 2) & 7) * 64 + (j >> 5) * 4 + (j & 3); }
+// activation vectors in LDS: element j -> plane p=(j>>2)&7, slot q=j>>5 (8 conflict-free ds_read_b128 per lane).  A plane
+// is 64 floats + 4 of padding: the ds_write_b32 of 32 consecutive elements then touches 32 distinct banks (with 64-float
+// planes the 8 planes of a 32-lane group alias onto 4 banks: 8-way conflict, 27 % of the LDS-active cycles in round 1).
+#define XB_PLANE 68
+#define XB_VEC (8 * XB_PLANE)
+__device__ __forceinline__ int perm(int j) { return ((j >> 2) & 7) * XB_PLANE + (j >> 5) * 4 + (j & 3); }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
@@ -134,7 +138,7 @@ __device__ __forceinline__ void dot32x3(const float *w, const float *vec, int q,
     for (int h = 0; h < 2; ++h) {
         float4 x[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = p[(4 * h + k) * 16];
+        for (int k = 0; k < 4; ++k) x[k] = p[(4 * h + k) * (XB_PLANE / 4)];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int kk = 4 * h + k;
@@ -157,7 +161,7 @@ __device__ __forceinline__ void dot32x3_mixed(const float *w, const float4 *wl_,
     for (int h = 0; h < 2; ++h) {
         float4 x[4], wn[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { x[k] = p[(4 * h + k) * 16]; wn[k] = wl_[(4 * h + k) * 256]; }
+        for (int k = 0; k < 4; ++k) { x[k] = p[(4 * h + k) * (XB_PLANE / 4)]; wn[k] = wl_[(4 * h + k) * 256]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int kk = 4 * h + k;
@@ -177,7 +181,7 @@ __device__ __forceinline__ float dot32(const float *w, const float *vec, int q) 
     f2 s0 = mk2(0.f, 0.f), s1 = mk2(0.f, 0.f);
     float4 x[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = p[k * 16];
+    for (int k = 0; k < 8; ++k) x[k] = p[k * (XB_PLANE / 4)];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         s0 = pkfma(mk2(w[4 * k + 0], w[4 * k + 1]), mk2(x[k].x, x[k].y), s0);
@@ -195,9 +199,9 @@ constexpr int L_GH1 = L_CSTA + 512 * 4;        // [3][512]  W_hh1.h1 + b_hh1 gat
 constexpr int L_CSTQ = L_GH1 + 1536;           // [16 quarters][16] b_hh1 rzn | b_hh2 rzn | b3 x2 | c2 rzn | c3 | c4
 constexpr int L_HAND = L_CSTQ + 256;           // [16 quarters][8]  S -> C: gh2 rzn | . | noise[2 parities][2]
 constexpr int L_MISC = L_HAND + 128;           // scratch words
-constexpr int L_XB = L_MISC + 64;              // 6 activation vectors x 512 (plane order)
+constexpr int L_XB = L_MISC + 64;              // 6 activation vectors x XB_VEC (plane order, padded planes)
 constexpr int XB_H1 = 0, XB_X2 = 1, XB_X3 = 2, XB_H2 = 3, XB_F1 = 4, XB_F2 = 5;
-constexpr int L_SW = L_XB + 6 * 512;           // [8 planes][256 S-threads][4]: the n-gate row of W_hh2 (32 weights / S thread)
+constexpr int L_SW = L_XB + 6 * XB_VEC;           // [8 planes][256 S-threads][4]: the n-gate row of W_hh2 (32 weights / S thread)
 constexpr int L_FC3 = L_SW + 8 * 256 * 4;      // [4 C-waves][2 rows][8 planes][64 lanes][4]
 constexpr int L_TOTAL = L_FC3 + 16384;
 static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         // previous launch left in `st`
         float h1_j = resume ? st[tid] : 0.0f;
         float xfeed = resume ? st[4096] : (a.x_init ? a.x_init[row] : 0.0f);   // x_{t-1} (:196)
-        xb[XB_H2 * 512 + pj] = resume ? st[512 + tid] : 0.0f;
+        xb[XB_H2 * XB_VEC + pj] = resume ? st[512 + tid] : 0.0f;
         for (int i = tid; i < 1536; i += T2_THREADS) gh1s[i] = resume ? st[1024 + i] : a.w[a.off.r1_bhh + i];
         if (tid == 0) misc_f[M_XF] = xfeed;
         // frame of the step being prepared, tracked incrementally by the S waves (for the per-frame C constants)
@@ -440,8 +444,8 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 const float ng = tanh_fast(fmaf(cA.w, xprev, cd.w) + rg * ghn);
                 h1_j = (1.0f - zg) * ng + zg * h1_j;
                 x2_j = xin + h1_j;
-                xb[XB_H1 * 512 + pj] = h1_j;
-                xb[XB_X2 * 512 + pj] = x2_j;
+                xb[XB_H1 * XB_VEC + pj] = h1_j;
+                xb[XB_X2 * XB_VEC + pj] = x2_j;
             }
             P2(0);
             __syncthreads();  // B1
@@ -449,12 +453,12 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 
             if (isC) {
                 // ---- phase B: GRU2 unit `unit` (:213-216); rows r,z,n of W_ih2[:, :512] . x2 ----
-                const float h2o = xb[XB_H2 * 512 + pu];
-                const float x2u = xb[XB_X2 * 512 + pu];
+                const float h2o = xb[XB_H2 * XB_VEC + pu];
+                const float x2u = xb[XB_X2 * XB_VEC + pu];
                 const float g2r = hand[0], g2z = hand[1], g2n = hand[2];
                 const float c2r = cstQ[8], c2z = cstQ[9], c2n = cstQ[10];
                 float gr, gz, gn;
-                dot32x3(wv, xb + XB_X2 * 512, q, gr, gz, gn);
+                dot32x3(wv, xb + XB_X2 * XB_VEC, q, gr, gz, gn);
                 gr = row_sum(gr) + c2r; gz = row_sum(gz) + c2z; gn = row_sum(gn) + c2n;
                 const float rg = sigmoid_fast(gr + g2r);
                 const float zg = sigmoid_fast(gz + g2z);
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 // ---- S: gh1 for the next step = W_hh1 . h1' + b_hh1, published for everyone ----
                 float sr, sz, sn;
                 __builtin_amdgcn_s_sleep(2);   // let the critical waves' x2 reads go first
-                dot32x3(wv, xb + XB_H1 * 512, q, sr, sz, sn);
+                dot32x3(wv, xb + XB_H1 * XB_VEC, q, sr, sz, sn);
                 sr = row_sum(sr) + cstQ[0]; sz = row_sum(sz) + cstQ[1]; sn = row_sum(sn) + cstQ[2];
                 if (q == 0) {
                     st_granule(mail, G_GH + par * 1536 + unit, epoch, __float_as_uint(sr));
@@ -477,8 +481,8 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             // ---- exchange 1 (all threads, granule tid): x3 = x + h2 ; h2' = x3 - x2 ----
             {
                 const float x3 = __uint_as_float(take_granule(mail, G_X3 + par * 512 + tid, epoch, dead, a.err, 11u));
-                xb[XB_X3 * 512 + pj] = x3;
-                xb[XB_H2 * 512 + pj] = x3 - x2_j;
+                xb[XB_X3 * XB_VEC + pj] = x3;
+                xb[XB_H2 * XB_VEC + pj] = x3 - x2_j;
             }
             P2(3);
             __syncthreads();  // B2
@@ -486,7 +490,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 
             if (isC) {
                 // ---- phase C: fc1 row `unit` (:217-218) ----
-                const float s = row_sum(dot32(wv + 128, xb + XB_X3 * 512, q)) + cstQ[11];
+                const float s = row_sum(dot32(wv + 128, xb + XB_X3 * XB_VEC, q)) + cstQ[11];
                 if (q == 0) st_granule(mail, G_F1 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
             } else {
                 // ---- S: sampling noise of step t+1 (C reads the other parity slot this step) ----
@@ -495,7 +499,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(5);
             // ---- exchange 2: fc1 outputs ----
             {
-                xb[XB_F1 * 512 + pj] = __uint_as_float(take_granule(mail, G_F1 + par * 512 + tid, epoch, dead, a.err, 12u));
+                xb[XB_F1 * XB_VEC + pj] = __uint_as_float(take_granule(mail, G_F1 + par * 512 + tid, epoch, dead, a.err, 12u));
             }
             P2(6);
             __syncthreads();  // B3
@@ -503,7 +507,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
 
             if (isC) {
                 // ---- phase D: fc2 row `unit` (:220-221) ----
-                const float s = row_sum(dot32(wv + 96, xb + XB_F1 * 512, q)) + cstQ[12];
+                const float s = row_sum(dot32(wv + 96, xb + XB_F1 * XB_VEC, q)) + cstQ[12];
                 if (q == 0) st_granule(mail, G_F2 + par * 512 + unit, epoch, __float_as_uint(fmaxf(s, 0.0f)));
             } else {
                 // ---- S: conditioning + noise of step t+1 ----
@@ -512,7 +516,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(8);
             // ---- exchange 3: fc2 outputs ----
             {
-                xb[XB_F2 * 512 + pj] = __uint_as_float(take_granule(mail, G_F2 + par * 512 + tid, epoch, dead, a.err, 13u));
+                xb[XB_F2 * XB_VEC + pj] = __uint_as_float(take_granule(mail, G_F2 + par * 512 + tid, epoch, dead, a.err, 13u));
             }
             P2(9);
             __syncthreads();  // B4
@@ -522,14 +526,14 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 // ---- phase E: fc3 rows + race (:223, :231-235) ----
                 float lg0, lg1;
                 {
-                    const float4 *xp = (const float4 *)(xb + XB_F2 * 512) + q;
+                    const float4 *xp = (const float4 *)(xb + XB_F2 * XB_VEC) + q;
                     const float4 *wp = (const float4 *)(lds + L_FC3) + (size_t)(wl * 2) * 8 * 64 + lane;
                     f2 pa = mk2(0.f, 0.f), pb = mk2(0.f, 0.f);
 #pragma unroll
                     for (int kk = 0; kk < 8; kk += 4) {
                         float4 x[4], wa[4], wb[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { x[k] = xp[(kk + k) * 16]; wa[k] = wp[(kk + k) * 64]; wb[k] = wp[(8 + kk + k) * 64]; }
+                        for (int k = 0; k < 4; ++k) { x[k] = xp[(kk + k) * (XB_PLANE / 4)]; wa[k] = wp[(kk + k) * 64]; wb[k] = wp[(8 + kk + k) * 64]; }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const f2 xl = mk2(x[k].x, x[k].y), xh = mk2(x[k].z, x[k].w);
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                     // gh2 for the next step = W_hh2 . h2' + b_hh2 -> hand-off slot of the paired C quarter (C read the
                     // old value back in phase B, three barriers ago)
                     float sr, sz, sn;
-                    dot32x3_mixed(wv + 96, swl, xb + XB_H2 * 512, q, sr, sz, sn);
+                    dot32x3_mixed(wv + 96, swl, xb + XB_H2 * XB_VEC, q, sr, sz, sn);
                     sr = row_sum(sr) + cstQ[3]; sz = row_sum(sz) + cstQ[4]; sn = row_sum(sn) + cstQ[5];
                     if (q == 0) { hand[0] = sr; hand[1] = sz; hand[2] = sn; }
                 }
@@ -662,7 +666,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         if (seg_end < a.steps) {   // hand the recurrent state to the next segment's launch
             if (g == 0) {
                 st[tid] = h1_j;
-                st[512 + tid] = xb[XB_H2 * 512 + pj];
+                st[512 + tid] = xb[XB_H2 * XB_VEC + pj];
                 for (int i = tid; i < 1536; i += T2_THREADS) st[1024 + i] = gh1s[i];
                 if (tid == 0) st[4096] = xfeed;
             }
@@ -670,7 +674,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         }
     }
     if (PROF && a.prof && lane == 0 && g == 0 && team == 0) {
-        for (int i = 0; i < 17; ++i) a.prof[wave * 17 + i] += prof_acc[i];
+        for (int i = 0; i < 17; ++i) a.prof[wave * WRNN_PROF_SLOTS + i] += prof_acc[i];
     }
 }
 

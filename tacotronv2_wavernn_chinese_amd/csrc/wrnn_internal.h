@@ -12,6 +12,7 @@
 #include "../../include/wavernn_amd.h"
 
 #define WRNN_MAX_UP 4
+#define WRNN_PROF_SLOTS 32   // phase-cycle counters per wave (WRNN_TEAM_PROF=1)
 #define WRNN_KTAB_MAXD 8
 
 // Dimensions derived from wrnn_config (WaveRNN.__init__, fatchord_version.py:93-129).
@@ -175,7 +176,7 @@ struct WrnnTeamArgs {
     unsigned long long *mail;  // [n_teams][WRNN_TEAM_MAIL_GRANULES]
     unsigned *ctl;             // [16] per-XCD arrival counters
     unsigned *err;
-    unsigned long long *prof;  // [8][17] phase cycle counters (developer instrumentation) or null
+    unsigned long long *prof;  // [8][WRNN_PROF_SLOTS] phase cycle counters (developer instrumentation) or null
 };
 
 // Batch kernel (loop_batch.hip): R = 4 * nq rows per team in lock-step on the matrix cores.
