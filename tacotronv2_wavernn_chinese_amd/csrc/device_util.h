@@ -23,8 +23,10 @@ __host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     return Philox4{c0, c1, c2, c3};
 }
 
-// uniform in (0,1): 24 random bits, never 0 or 1
-__host__ __device__ inline float u01_from_bits(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// uniform in (0,1): 23 random bits, never 0 or 1.  (m + 0.5) * 2^-23 with m < 2^23 is exact in fp32; with 24 bits the
+// top value 2^24 - 0.5 rounds to 2^24, i.e. u == 1, -log u == 0 and a class of probability zero wins the race once per
+// 2^24 draws -- found by the 110 275-step Philox parity test (8 such draws in 113 M).
+__host__ __device__ inline float u01_from_bits(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 // The uniform draw for (step t, row, element k): element k of the 1024 RAW
 // classes, or k < 10 mixture uniforms / k == 10 logistic uniform for MOL.

@@ -65,14 +65,11 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_a
 // Weights parked in the accumulator half of the register file ("a" constraint = AGPR class for the value's whole life):
 // hipcc allocates at most 256 architectural VGPRs per wave and uses AGPRs only as spill slots, so 320 weights + working set
 // as plain floats overflow into scratch (129 registers, reloaded on the serial chain: measured 13 000 cycles in phase B).
-// Parked explicitly, a weight costs one v_accvgpr_read per use (+ the 2 wait states a VALU-written VGPR needs before an
-// MFMA reads it, which the hazard recognizer cannot add behind inline asm).
+// A value of AGPR class feeds the MFMA's A operand directly (`v_mfma_f32_4x4x1_16b_f32 a[0:3], a93, v9, a[0:3]`: the operand
+// class of the builtin is "VGPR or AGPR").  Fetching it into a VGPR first (v_accvgpr_read) costs ~20 cycles per MFMA instead
+// of 8: the read waits for the in-flight MFMAs that write accumulators (measured: 4 046 vs ~1 700 cycles for W_hh1 at R = 8).
 __device__ __forceinline__ void apark(float &dst, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
-__device__ __forceinline__ float aget(const float &a) {
-    float v;
-    asm volatile("v_accvgpr_read_b32 %0, %1\n\ts_nop 1" : "=v"(v) : "a"(a));
-    return v;
-}
+__device__ __forceinline__ float aget(const float &a) { return a; }
 template <bool AG>
 __device__ __forceinline__ float wget(const float &w) { return AG ? aget(w) : w; }
 
@@ -567,8 +564,6 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             PB(15);  // fc2 + publish
             prep_noise(t);
             PB(16);  // noise
-            if (t + 1 < a.steps) prep_cond(t + 1);
-            PB(17);  // conditioning of the next step
             {
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u + (unsigned)tid * 16u};
@@ -580,7 +575,11 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             __syncthreads();   // B4
             PB(19);
 
-            // ================= window 5: phase E (fc3 :223 + sampler :225-237) | race =================
+            // ================= window 5: conditioning of the next step | phase E (fc3 :223 + sampler :225-237) | race =================
+            // (the record loads are issued here, a whole window after the last publish: a wait on them directly behind a
+            // granule store also waits for that store's acknowledgement -- stores count in vmcnt on gfx9 -- measured 2 281 cycles)
+            if (t + 1 < a.steps) prep_cond(t + 1);
+            PB(17);  // conditioning of the next step
             {
                 float lg0 = 0.f, lg1 = 0.f;
                 if (wg_has_fc3) {

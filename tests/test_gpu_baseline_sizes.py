@@ -84,11 +84,7 @@ def test_config1_b1_t401_philox_production_mode():
     res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=seed)
     got = res['labels'].cpu().numpy().T
     L = got.shape[0]
-    q = np.empty((L, 1, 1024), np.float32)
-    for t0 in range(0, L, 8192):   # host replay of the device RNG in chunks (memory)
-        n = min(8192, L - t0)
-        u = _philox_chunk(seed, t0, n, [0])
-        q[t0:t0 + n] = (-np.log(u.astype(np.float64))).astype(np.float32)
+    q = _philox_q(seed, L, [0])
     om = orc.OracleModel(sd, fast=True)
     cm, ca = om.conditioning(mels)
     ref = om.loop(cm, ca, orc.NOISE_EXPO, q)
@@ -100,20 +96,16 @@ def test_config1_b1_t401_philox_production_mode():
     assert len(np.unique(got)) > 100
 
 
-def _philox_chunk(seed, t0, n, rows):
-    """philox_uniform_raw for steps [t0, t0+n) and the given GLOBAL row indices -> (n, len(rows), 1024)."""
-    from tests.philox_ref import _philox
-    t = np.arange(t0, t0 + n, dtype=np.uint64)
-    th = (t >> np.uint64(1))[:, None, None]
-    r = np.asarray(rows, dtype=np.uint32)[None, :, None]
-    k2 = np.arange(512, dtype=np.uint32)[None, None, :]
-    shape = (n, len(rows), 512)
-    c0 = np.broadcast_to((th & np.uint64(0xFFFFFFFF)).astype(np.uint32), shape)
-    c1 = np.broadcast_to((th >> np.uint64(32)).astype(np.uint32), shape)
-    x, y, z, w = _philox((c0, c1, np.broadcast_to(r, shape), np.broadcast_to(k2, shape)), (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
-    odd = (t & np.uint64(1)).astype(bool)[:, None, None]
-    bits = np.stack([np.where(odd, z, x), np.where(odd, w, y)], axis=-1).reshape(n, len(rows), 1024)
-    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+def _philox_q(seed, L, rows, chunk=4096):
+    """Exp(1) draws q = -log(u) of the device's Philox stream for steps [0, L) and the given GLOBAL rows, replayed with torch
+    on the GPU (float64 log), as a float32 numpy array (L, len(rows), 1024) for the oracle."""
+    from tests.philox_ref import philox_uniform_raw_torch
+    q = np.empty((L, len(rows), 1024), np.float32)
+    for t0 in range(0, L, chunk):
+        n = min(chunk, L - t0)
+        u = philox_uniform_raw_torch(seed, t0, n, rows, device='cuda')
+        q[t0:t0 + n] = (-torch.log(u.to(torch.float64))).to(torch.float32).cpu().numpy()
+    return q
 
 
 def test_config2_b64_sampled_batch_kernel():
@@ -134,10 +126,7 @@ def test_config2_b64_sampled_batch_kernel():
     L = lab.shape[1]
     assert lab.shape == (B, T * 275)
     rows = [0, 9, 18, 27, 36, 45, 54, 63]
-    q = np.empty((L, len(rows), 1024), np.float32)
-    for t0 in range(0, L, 2048):
-        n = min(2048, L - t0)
-        q[t0:t0 + n] = (-np.log(_philox_chunk(seed, t0, n, rows).astype(np.float64))).astype(np.float32)
+    q = _philox_q(seed, L, rows)
     om = orc.OracleModel(sd, fast=True)
     cm, ca = om.conditioning(mels[rows])
     ref = om.loop(cm, ca, orc.NOISE_EXPO, q)

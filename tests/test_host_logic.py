@@ -192,3 +192,18 @@ def test_bench_launches_its_own_ranks(tmp_path):
     else:
         assert r.returncode != 0
         assert r.stderr.count('no HIP device visible') >= 2 or 'invalid device ordinal' in r.stderr, r.stderr[-2000:]
+
+
+def test_philox_replays_agree():
+    """The numpy and the torch replay of the device RNG (tests/philox_ref.py) are two implementations of one specification:
+    identical uniforms, strictly inside (0, 1)."""
+    from tests.philox_ref import philox_uniform_raw, philox_uniform_raw_torch
+    seed = 0x1234ABCD5678
+    a = philox_uniform_raw(seed, 70, 3, 1024)
+    b = philox_uniform_raw_torch(seed, 0, 70, [0, 1, 2]).numpy()
+    np.testing.assert_array_equal(a, b)
+    c = philox_uniform_raw_torch(seed, 33, 37, [2, 0]).numpy()
+    np.testing.assert_array_equal(c, a[33:, [2, 0]])
+    assert a.min() > 0.0 and a.max() < 1.0
+    u_top = ((np.uint32(0xFFFFFFFF) >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    assert u_top < 1.0
