@@ -57,6 +57,7 @@ def _has_avx2() -> bool:
 
 
 _libs: Dict[str, C.CDLL] = {}
+_HW_THREADS: Optional[int] = None
 
 
 def _lib(fast: bool = False) -> C.CDLL:
@@ -206,8 +207,15 @@ class OracleModel:
         logits = np.empty((L, B, NC), dtype=np.float32) if want_logits else None
         margin = np.empty((L, B), dtype=np.float32)
         runner = np.empty((L, B), dtype=np.int32)
-        if num_threads is not None:
-            self.lib.wo_set_num_threads(int(num_threads))
+        # The per-step parallel regions are tiny (one matvec each): more than ~16 OpenMP threads only add fork/join and
+        # barrier time -- on a many-core host (the GPU box exposes all its logical CPUs to the default team) the loop ran
+        # ~10x slower than with 16 threads.  Default: min(hardware threads, 16).
+        global _HW_THREADS
+        if _HW_THREADS is None:
+            _HW_THREADS = max(1, min(int(self.lib.wo_num_threads()), os.cpu_count() or 1))
+        if num_threads is None:
+            num_threads = min(_HW_THREADS, 16)
+        self.lib.wo_set_num_threads(int(num_threads))
         rc = self.lib.wo_loop(C.byref(self.dims), C.byref(self.w), _p(cond_m), _p(cond_a), B, C.c_long(L),
                               noise_mode, _p(noise1), _p(noise2), _p(x_forced), _p(labels, C.c_int32),
                               _p(samples), _p(logits), _p(margin), _p(runner, C.c_int32))
@@ -215,7 +223,11 @@ class OracleModel:
         return dict(labels=labels, samples=samples, logits=logits, margin=margin, runner=runner)
 
     def num_threads(self) -> int:
-        return int(self.lib.wo_num_threads())
+        """Hardware threads OpenMP would use by default (before any cap applied by ``loop``)."""
+        global _HW_THREADS
+        if _HW_THREADS is None:
+            _HW_THREADS = max(1, min(int(self.lib.wo_num_threads()), os.cpu_count() or 1))
+        return _HW_THREADS
 
 
 class _DmModel(C.Structure):
@@ -251,6 +263,7 @@ class DeepmindOracle:
         fine = np.empty(seq_len, np.int32)
         margin = np.empty((seq_len, 2), np.float32)
         runner = np.empty((seq_len, 2), np.int32)
+        self.lib.wo_set_num_threads(min(max(1, min(int(self.lib.wo_num_threads()), os.cpu_count() or 1)), 16))
         rc = self.lib.wo_dm_generate(C.byref(self.m), C.c_long(seq_len), _p(noise), _p(coarse, C.c_int32), _p(fine, C.c_int32),
                                      _p(margin), _p(runner, C.c_int32))
         assert rc == 0

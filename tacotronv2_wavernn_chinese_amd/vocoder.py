@@ -300,6 +300,43 @@ class WaveRNN(nn.Module):
         self.train()
         return output
 
+    def generate_many(self, mels_list, save_paths=None, mu_law=True, **native_opts):
+        """Extension for serving loops: several independent utterances of different lengths in ONE device call, so that all
+        8 XCD teams of the GPU work (a single unbatched utterance keeps one team = 1/8 of the chip busy; up to 8 utterances
+        run on the latency kernel one per team, more on the batch kernel).  ``mels_list``: sequence of (n_mels, T_i) arrays.
+        The clips are zero-padded on the right to the longest one -- exactly the padding ``generate`` itself applies
+        (``pad_tensor``, :183) -- every row is generated for max(T_i) frames and trimmed afterwards, so the first
+        T_i * hop samples of row i are what a single ``generate`` call on clip i computes for the same noise.  Returns a list
+        of float64 arrays, each what ``generate(mels_i[None], path_i, False, ...)`` returns ((T_i - 1) * hop samples, mu-law
+        decoded, 20-hop fade-out); writes the wavs when ``save_paths`` is given."""
+        self.eval()
+        mu_law = mu_law if self.mode == 'RAW' else False
+        arrs = [np.asarray(torch.as_tensor(m).detach().cpu().numpy(), dtype=np.float32) for m in mels_list]
+        if not arrs or any(a.ndim != 2 or a.shape[0] != self.feat_dims for a in arrs):
+            raise ValueError(f'expected a non-empty sequence of (n_mels={self.feat_dims}, T_i) arrays')
+        lens = [a.shape[1] for a in arrs]
+        tmax = max(lens)
+        batch = np.zeros((len(arrs), self.feat_dims, tmax), np.float32)
+        for i, a in enumerate(arrs):
+            batch[i, :, :lens[i]] = a
+        if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) == _cabi.NOISE_PHILOX:
+            native_opts['seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
+        res = self.generate_raw(batch, False, 11000, 550, **native_opts)
+        samples = res['samples'].cpu().numpy().astype(np.float64)
+        outs = []
+        for i, t_i in enumerate(lens):
+            wave_len = (t_i - 1) * self.hop_length
+            out = samples[i, :t_i * self.hop_length]
+            if mu_law:
+                out = decode_mu_law(out, self.n_classes, False)
+            out = out[:wave_len]
+            out[-20 * self.hop_length:] *= np.linspace(1, 0, 20 * self.hop_length)   # raises for T_i < 21, like :258
+            if save_paths is not None:
+                save_wav(out, save_paths[i], self.sample_rate)
+            outs.append(out)
+        self.train()
+        return outs
+
     def gen_display(self, i, seq_len, b_size, start):
         """The reference's own ksamples/s meter (:267-271)."""
         gen_rate = (i + 1) / (time.time() - start) * b_size / 1000

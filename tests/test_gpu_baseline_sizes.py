@@ -218,3 +218,25 @@ def test_raw_9bit_has_no_phantom_classes(kernel):
     smp = res['samples'].cpu().numpy().T
     np.testing.assert_array_equal(smp, 2.0 * got.astype(np.float32) / np.float32(511.0) - np.float32(1.0))
     assert label_stats(got, ref['labels'], first)['max_abs'] <= 1
+
+
+def test_generate_many_fills_the_teams_with_ragged_utterances(tmp_path):
+    """Serving extension: 5 utterances of different lengths in one device call (one per XCD team on the latency kernel).
+    Row i, trimmed to its own length, must be what a single generate() call on clip i gives for the same noise."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
+    sd = make_state_dict(0, variant='peaky')
+    m = _model(sd)
+    lens = [21, 33, 27, 40, 22]
+    clips = [make_mels(300 + i, 1, t)[0] for i, t in enumerate(lens)]
+    tmax = max(lens)
+    rng = np.random.Generator(np.random.PCG64(77))
+    q = rng.standard_exponential((tmax * 275, len(lens), 1024)).astype(np.float32)
+    outs = m.generate_many(clips, [tmp_path / f'{i}.wav' for i in range(len(lens))], True, noise_mode=_cabi.NOISE_INJECTED, noise1=q)
+    assert m.last_timing['kernel'] == _cabi.KERNEL_TEAM2 and m.last_timing['rows'] == len(lens)
+    for i, t in enumerate(lens):
+        assert outs[i].shape == ((t - 1) * 275,) and outs[i].dtype == np.float64
+        single = m.generate(clips[i][None], tmp_path / 's.wav', False, 11000, 550, True, noise_mode=_cabi.NOISE_INJECTED,
+                            noise1=np.ascontiguousarray(q[:t * 275, i:i + 1]))
+        np.testing.assert_array_equal(outs[i], single)
+        assert (tmp_path / f'{i}.wav').exists()
