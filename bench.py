@@ -128,6 +128,9 @@ def main() -> int:
     ap.add_argument('--batch', type=int, default=0, help='rows per GPU (default: the config\'s)')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'batch', 'simple'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-dry-run', action='store_true',
+                    help='exercise the launcher / rendezvous / collectives / timing / JSON scaffolding on CPU (gloo) with a stand-in for the '
+                         'device calls: tests only, the line it prints is not a measurement')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -145,14 +148,21 @@ def main() -> int:
     from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_mels, make_state_dict
     from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
 
-    if not torch.cuda.is_available():
-        print('bench.py: no HIP device visible (the hot path has no CPU fallback)', file=sys.stderr)
-        return 3
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+    dry = args.cpu_dry_run
+    if dry:
+        dev = torch.device('cpu')
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo')
+    else:
+        if not torch.cuda.is_available():
+            print('bench.py: no HIP device visible (the hot path has no CPU fallback)', file=sys.stderr)
+            return 3
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('nccl', device_id=dev)
 
     cfg = CONFIGS[args.config]
     mode, B = cfg['mode'], (args.batch or cfg['batch'])
@@ -163,7 +173,8 @@ def main() -> int:
     model = WaveRNN(**dims, mode=mode)
     model.verbose = False
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
-    model.to(dev)
+    if not dry:
+        model.to(dev)
     model.kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[args.kernel]
     T = args.frames
     scatter = args.config == 3
@@ -174,20 +185,25 @@ def main() -> int:
         all_mels, mels = None, torch.empty((B, 80, T), dtype=torch.float32, device=dev)
     else:
         mels = torch.from_numpy(make_mels(1000 + rank, B, T)).to(dev)       # resident in HBM before timing
-    nat = model.native()
-    rows, L = nat.plan(B, T, False, 11000, 550)
+    nat = None if dry else model.native()
+    rows, L = (B, T * HOP) if dry else nat.plan(B, T, False, 11000, 550)
     samples = torch.empty((rows, L), dtype=torch.float32, device=dev)
     labels = torch.empty((rows, L), dtype=torch.int32, device=dev)
     wave_len = (T - 1) * HOP
     wave = torch.empty((rows, wave_len), dtype=torch.float64, device=dev)   # what generate() returns (:264), per utterance
     gathered = [torch.empty((rows, wave_len), dtype=torch.float64, device=dev) for _ in range(world)] if (scatter and rank == 0) else None
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = 0 if dry else torch.cuda.current_stream(dev).cuda_stream
 
     def one_step(i: int):
         if scatter and world > 1:
             dist.scatter(mels, list(all_mels.view(world, B, 80, T).unbind(0)) if rank == 0 else None, src=0)
         elif scatter:
             mels.copy_(all_mels)
+        if dry:   # stand-in for the device calls: every utterance's "waveform" is a function of its own mel only
+            wave.copy_(mels.to(torch.float64).sum(dim=(1, 2))[:, None].expand(rows, wave_len))
+            if scatter and world > 1:
+                dist.gather(wave, gathered, dst=0)
+            return
         nat.generate(mels.data_ptr(), B, T, False, 11000, 550, labels_ptr=labels.data_ptr(),
                      samples_ptr=samples.data_ptr(), stream=stream, noise_mode=_cabi.NOISE_PHILOX,
                      seed=0xC0FFEE + 7919 * i + rank, kernel=model.kernel)
@@ -200,10 +216,12 @@ def main() -> int:
             dist.gather(wave, gathered, dst=0)
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
         one_step(-1 - i)
@@ -213,7 +231,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
-        tm = nat.last_timing()          # waits for this step's kernels (HIP events on the launch stream)
+        tm = dict(kernel=0, loop_ms=1.0, prologue_ms=0.0, launches=1) if dry else nat.last_timing()   # waits for this step's kernels (HIP events on the launch stream)
         loop_ms.append(tm['loop_ms'])
         pro_ms.append(tm['prologue_ms'])
     barrier()
@@ -266,7 +284,13 @@ def main() -> int:
                        'parallelism': f'utterance-parallel x{world} (no data-path collective' + (' but the scatter/gather of clips)' if scatter else ')')},
             'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if dry:
+            out['data'] = 'dry-run (CPU stand-in for the device calls: not a measurement)'
+            if scatter and world > 1:   # every rank's waveforms came back, and they are the ones of the clips it was sent
+                want = all_mels.view(world, B, 80, T).to(torch.float64).sum(dim=(2, 3))
+                ok = all(torch.equal(gathered[r][:, 0], want[r]) for r in range(world))
+                out['dry_run_check'] = 'ok' if ok else 'MISMATCH'
+        if world == 1 and not args.no_cpu_baseline and not dry:
             try:
                 out['cpu_baseline'] = cpu_baseline()
             except Exception as e:  # the baseline must never sink the bench line

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 
@@ -55,3 +56,28 @@ def test_single_process_path():
     from tacotronv2_wavernn_chinese_amd.sharding import generate_sharded
     out = generate_sharded(lambda i, m: np.array([i, m.sum()]), [np.ones((2, 2)), np.zeros((2, 2))])
     assert [o.tolist() for o in out] == [[0, 4.0], [1, 0.0]]
+
+
+def test_bench_distributed_scaffolding_dry_run(tmp_path):
+    """`python bench.py --gpus 2 --config 3` end to end on CPU (gloo) with a stand-in for the device calls: self-launch of the
+    ranks, rendezvous on 127.0.0.1, scatter of the clips from rank 0, gather of the waveforms, barrier + MAX-over-ranks timing,
+    one JSON line from rank 0 whose gathered waveforms belong to the clips each rank was sent."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    for cfg in ('3', '1'):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--cpu-dry-run', '--config', cfg, '--steps', '2',
+                            '--warmup', '1', '--frames', '21', '--batch', '3' if cfg == '3' else '0'],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['unit'] == 'ksamples/s'
+        assert d['data'].startswith('dry-run')
+        if cfg == '3':
+            assert d['dry_run_check'] == 'ok'
+            assert d['value'] == pytest.approx(2 * 2 * 3 * 21 * 275 / (d['ms_per_step'] * 2 / 1e3) / 1e3, rel=1e-3)
