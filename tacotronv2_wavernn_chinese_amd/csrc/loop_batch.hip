@@ -142,13 +142,26 @@ constexpr int M_DEAD = 0, M_TEAM = 1, M_RANK = 2;
 // what wave wl of EVERY workgroup published for row quad rq).  Every load of every vector is in flight at once -- one L2
 // round trip when the producers are done, which they normally are: the shadow work of the window sits between the publish
 // and this poll -- and only slices that came back incomplete are read again.
+// PRE: the caller already requested every slice once (gather_issue, in the middle of the shadow work of the window, when the
+// producers are normally done): the first look then costs no round trip of its own.
 template <int NM, int NV>
-__device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, const unsigned (&byteoff)[NV], unsigned tag, u4v (&g)[NV][NM],
-                                            bool &dead, unsigned *err, unsigned code) {
+__device__ __forceinline__ void gather_issue(__amdgpu_buffer_rsrc_t rs, const unsigned (&byteoff)[NV], u4v (&g)[NV][NM]) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, byteoff[v] + m * 4096u);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int NM, int NV, bool PRE = false>
+__device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, const unsigned (&byteoff)[NV], unsigned tag, u4v (&g)[NV][NM],
+                                            bool &dead, unsigned *err, unsigned code) {
+    if (!PRE) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, byteoff[v] + m * 4096u);
+    }
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
@@ -168,10 +181,10 @@ __device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, const uns
 }
 
 // acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane]
-template <int NQ, int NG, bool AG>
+template <int NQ, int NG, bool AG, int S0 = 0, int S1 = 8>
 __device__ __forceinline__ void mfma_gates(const float *w, const f4 *xv, int lane, f4 (&acc)[NG][NQ]) {
 #pragma unroll
-    for (int S = 0; S < 8; ++S) {
+    for (int S = S0; S < S1; ++S) {
         f4 b[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64 + lane];
@@ -360,6 +373,36 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             cd.z = fmaf(k4, a5.z, fmaf(k3, a4.w, fmaf(k2, a4.x, fmaf(k1, a3.y, fmaf(k0, a2.z, a0.z)))));
             cd.w = fmaf(k4, a5.w, fmaf(k3, a5.x, fmaf(k2, a4.y, fmaf(k1, a3.z, fmaf(k0, a2.w, a0.w)))));
         };
+        // R = 4 only (the 8-row kernel has no registers to spare): the same conditioning with its loads issued one step ahead.
+        // The record (24 floats) stays in registers and is re-read only when the frame changes, the 5 taps of step t + 2 are
+        // requested while the values of step t + 1 are combined, so no load latency is waited for (measured: 2 150 cycles per
+        // step when the loads are waited for where they are issued).
+        float4 ra0, ra1, ra2, ra3, ra4, ra5;
+        float rk0 = 0.f, rk1 = 0.f, rk2 = 0.f, rk3 = 0.f, rk4 = 0.f;
+        ra0 = ra1 = ra2 = ra3 = ra4 = ra5 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int rec_frame = -1000000, fetched_frame = -1;
+        auto cond_fetch = [&](int64_t ts) {
+            const int64_t pos = rw.start + ts;
+            const bool live = pos < a.total_len;
+            const int fi = live ? nfi : T;
+            const int ph = live ? nph : 0;
+            if (++nph == HOP) { nph = 0; ++nfi; }
+            fetched_frame = fi;
+            if (fi != rec_frame) {
+                const float4 *r = (const float4 *)(recb + (size_t)fi * 512 * 32);
+                ra0 = r[0]; ra1 = r[1]; ra2 = r[2]; ra3 = r[3]; ra4 = r[4]; ra5 = r[5];
+                rec_frame = fi;
+            }
+            const float *kt = ktab + ph * 5;
+            rk0 = kt[0]; rk1 = kt[1]; rk2 = kt[2]; rk3 = kt[3]; rk4 = kt[4];
+        };
+        auto cond_combine = [&]() {
+            pend_frame = fetched_frame;
+            cd.x = fmaf(rk4, ra2.x, fmaf(rk3, ra1.w, fmaf(rk2, ra1.z, fmaf(rk1, ra1.y, fmaf(rk0, ra1.x, ra0.x)))));
+            cd.y = fmaf(rk4, ra5.y, fmaf(rk3, ra4.z, fmaf(rk2, ra3.w, fmaf(rk1, ra3.x, fmaf(rk0, ra2.y, ra0.y)))));
+            cd.z = fmaf(rk4, ra5.z, fmaf(rk3, ra4.w, fmaf(rk2, ra4.x, fmaf(rk1, ra3.y, fmaf(rk0, ra2.z, ra0.z)))));
+            cd.w = fmaf(rk4, ra5.w, fmaf(rk3, ra5.x, fmaf(rk2, ra4.y, fmaf(rk1, ra3.z, fmaf(rk0, ra2.w, ra0.w)))));
+        };
         // per-frame constants of (unit, row) once the frame changed: c2 (r,z,n), c3, c4 (record slots 24..28)
         auto frame_consts = [&]() {
             if (pend_frame != cst_frame) {
@@ -398,7 +441,13 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 } else { nz0 = pz0; nz1 = pz1; }
             } else { nz0 = 0.f; nz1 = 0.f; }
         };
-        prep_cond(0);
+        if (NQ == 1) {
+            cond_fetch(0);
+            cond_combine();
+            if (a.steps > 1) cond_fetch(1);
+        } else {
+            prep_cond(0);
+        }
         __syncthreads();
 
         for (int64_t t = 0; t < a.steps; ++t) {
@@ -425,7 +474,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             PB(0);   // phase A + publish
             {
                 // (both vectors in flight at once would save one L2 round trip, but the 2 x NM x 4 registers of it push the
-                // R = 8 kernel into scratch spills: measured with -Rpass-analysis, 130 vs 17 registers)
+                // kernel into scratch spills: measured with -Rpass-analysis, R = 8: 130 vs 17 registers, R = 4: 13 vs 0)
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_X2 + par * L::RG) * 8u + (unsigned)tid * 16u};
                 gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 21u);
@@ -472,19 +521,26 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                mfma_gates<NQ, 3, true>(wa, vH1, lane, acc);
+                u4v gx[1][NM];
+                const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u + (unsigned)tid * 16u};
+                if (NQ == 1) {
+                    // R = 4: the x3 slices are requested half way through the shadow MFMAs (the producers are normally done by
+                    // then), so their L2 round trip runs under the second half instead of after it
+                    mfma_gates<NQ, 3, true, 0, 4>(wa, vH1, lane, acc);
+                    gather_issue<NM, 1>(mrs, offs, gx);
+                    mfma_gates<NQ, 3, true, 4, 8>(wa, vH1, lane, acc);
+                } else {
+                    mfma_gates<NQ, 3, true>(wa, vH1, lane, acc);
+                }
                 PB(7);   // W_hh1 MFMAs issued
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
                     if (q == 0 || my_rq == q) { gh1r = fr + cst[C_H1R * 256]; gh1z = fz + cst[C_H1Z * 256]; gh1n = fn + cst[C_H1N * 256]; }
                 }
-            }
-            PB(8);   // W_hh1 folded
-            {
-                u4v gx[1][NM];
-                const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u + (unsigned)tid * 16u};
-                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 23u);
+                PB(8);   // W_hh1 folded
+                if (NQ == 1) gather_vecs<NM, 1, true>(mrs, offs, epoch, gx, dead, a.err, 23u);
+                else gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 23u);
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
@@ -514,8 +570,11 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 const f4 *wnl = (const f4 *)(lds + L::L_WN) + (size_t)wl * 8 * 64 + lane;
+                u4v gx[1][NM];
+                const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u + (unsigned)tid * 16u};
 #pragma unroll
                 for (int S = 0; S < 8; ++S) {
+                    if (NQ == 1 && S == 4) gather_issue<NM, 1>(mrs, offs, gx);   // R = 4: fc1 slices requested half way (see window 2)
                     f4 b[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64 + lane] - vP[(q * 8 + S) * 64 + lane];
@@ -536,12 +595,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
                     if (q == 0 || my_rq == q) { gh2r = fr + cst[C_H2R * 256]; gh2z = fz + cst[C_H2Z * 256]; gh2n = fn + cst[C_H2N * 256]; }
                 }
-            }
-            PB(12);  // W_hh2
-            {
-                u4v gx[1][NM];
-                const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u + (unsigned)tid * 16u};
-                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 24u);
+                PB(12);  // W_hh2
+                if (NQ == 1) gather_vecs<NM, 1, true>(mrs, offs, epoch, gx, dead, a.err, 24u);
+                else gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 24u);
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
@@ -578,7 +634,14 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 5: conditioning of the next step | phase E (fc3 :223 + sampler :225-237) | race =================
             // (the record loads are issued here, a whole window after the last publish: a wait on them directly behind a
             // granule store also waits for that store's acknowledgement -- stores count in vmcnt on gfx9 -- measured 2 281 cycles)
-            if (t + 1 < a.steps) prep_cond(t + 1);
+            if (NQ == 1) {
+                if (t + 1 < a.steps) {
+                    cond_combine();                            // step t + 1 from what was requested a step ago
+                    if (t + 2 < a.steps) cond_fetch(t + 2);    // lands during the next step
+                }
+            } else if (t + 1 < a.steps) {
+                prep_cond(t + 1);
+            }
             PB(17);  // conditioning of the next step
             {
                 float lg0 = 0.f, lg1 = 0.f;
