@@ -34,3 +34,32 @@ def test_create_rejects_bad_config_without_gpu():
         _cabi.NativeVocoder(rnn_dims=256, fc_dims=512, bits=10, pad=2, upsample_factors=(5, 5, 11), feat_dims=80,
                             compute_dims=128, res_out_dims=128, res_blocks=10, hop_length=275, sample_rate=22050,
                             mode='RAW', device=0)
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The ctypes mirrors in _cabi.py against the C header itself: a C program that includes include/wavernn_amd.h prints
+    sizeof / offsetof of every field; a field added on one side only (or reordered) fails here, not as silent garbage in a
+    device call."""
+    import ctypes as C
+    import os
+    import subprocess
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {'wrnn_config': _cabi.Config, 'wrnn_tensor_desc': _cabi.TensorDesc, 'wrnn_sample_opts': _cabi.SampleOpts,
+               'wrnn_timing': _cabi.Timing}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root}/include/wavernn_amd.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c11', '-o', str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True).split('\n')
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, st in structs.items():
+        assert got[(cname, 'size')] == C.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert got[(cname, fname)] == getattr(st, fname).offset, (cname, fname)
