@@ -119,9 +119,9 @@ struct Lay {
     static constexpr int L_FC3 = 0;                // [4 waves][2 sets][8 S][64 lanes][4 e]: A operands of the fc3 slice
     static constexpr int L_WN = 16384;             // [4 waves][8 S][64 lanes][4 e]: A operands of gate n of W_hh2 (shadow path)
     static constexpr int L_CST = L_WN + 8192;      // [12][256]: per-thread constants (read once per step, not worth registers)
-    static constexpr int L_P = L_CST + 12 * 256;   // x2, then h2' = x3 - x2 (in place), later fc2 outputs
+    static constexpr int L_P = L_CST + 12 * 256;   // x2, later fc2 outputs
     static constexpr int L_Q = L_P + VEC;          // x3
-    static constexpr int L_H1 = L_Q + VEC;         // h1', later fc1 outputs
+    static constexpr int L_H1 = L_Q + VEC;         // h1', later fc1 outputs        (h2' = x3 - x2 is formed on the fly)
     static constexpr int L_XN = L_H1 + VEC;        // [16] x_{t-1} of every batch row
     static constexpr int L_MISC = L_XN + 16;       // [16]
     static constexpr int L_TOTAL = L_MISC + 16;
@@ -136,7 +136,7 @@ struct Lay {
 };
 // slots of L_CST
 constexpr int C_A0 = 0, C_A1 = 1, C_A2 = 2, C_A3 = 3, C_B30 = 4, C_B31 = 5, C_H1R = 6, C_H1Z = 7, C_H1N = 8, C_H2R = 9, C_H2Z = 10, C_H2N = 11;
-constexpr int M_DEAD = 0, M_TEAM = 1, M_RANK = 2, M_PBDONE = 4;   // M_PBDONE: waves that finished reading x2 in phase B (monotonic)
+constexpr int M_DEAD = 0, M_TEAM = 1, M_RANK = 2;
 
 // All-gather of NV published vectors (R x 512 granules each, mailbox order [rq][wl][S][iu][j][e]; slice m = (rq, wl) holds
 // what wave wl of EVERY workgroup published for row quad rq).  Every load of every vector is in flight at once -- one L2
@@ -498,9 +498,6 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 mfma_gates<NQ, 3, false>(wv, vP, lane, acc);
-                // this wave has read x2 for the last time: the buffer may be overwritten with h2' = x3 - x2 once all 4 waves say so
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_fetch_add(&misc_i[M_PBDONE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 PB(4);   // phase B MFMAs issued
                 float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -544,23 +541,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 PB(8);   // W_hh1 folded
                 if (NQ == 1) gather_vecs<NM, 1, true>(mrs, offs, epoch, gx, dead, a.err, 23u);
                 else gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 23u);
-                {
-                    // x2 is dead once every wave of the workgroup is past its phase-B reads (they normally are, thousands of cycles
-                    // ago): h2' = x3 - x2 replaces it in place (each thread rewrites exactly the elements it wrote in window 1)
-                    unsigned spins = 0;
-                    while (!dead && __hip_atomic_load(&misc_i[M_PBDONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(4u * epoch)) {
-                        if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 28u); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const float2 x2v = *(const float2 *)(lds + L::L_P + pair_dst(m));
-                    const float x3a = __uint_as_float(gx[0][m].x), x3b = __uint_as_float(gx[0][m].z);
-                    *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(x3a, x3b);
-                    *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(x3a - x2v.x, x3b - x2v.y);   // h2' = x3 - x2
-                }
+                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
             PB(9);   // x3 gathered
             __syncthreads();   // B2
@@ -580,8 +562,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             }
             PB(11);  // fc1 + publish
             {
-                // off the serial chain: gh2 of the next step = W_hh2 . h2' + b_hh2 (h2' = x3 - x2 took the place of x2 when x3
-                // arrived: the same subtraction team2 does); gate n's weights come from LDS
+                // off the serial chain: gh2 of the next step = W_hh2 . h2' + b_hh2, h2' = x3 - x2 formed on the fly from the two
+                // gathered vectors (the same subtraction team2 does when x3 arrives); gate n's weights come from LDS
                 f4 acc[3][NQ];
 #pragma unroll
                 for (int gt = 0; gt < 3; ++gt)
@@ -595,7 +577,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     if (NQ == 1 && S == 4) gather_issue<NM, 1>(mrs, offs, gx);   // R = 4: fc1 slices requested half way (see window 2)
                     f4 b[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) b[q] = vP[(q * 8 + S) * 64 + lane];
+                    for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64 + lane] - vP[(q * 8 + S) * 64 + lane];
                     const f4 wn = wnl[S * 64];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
