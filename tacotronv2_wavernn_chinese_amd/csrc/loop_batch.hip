@@ -57,9 +57,11 @@ __device__ __forceinline__ void st_granule(u64 *base, unsigned idx, unsigned tag
     const unsigned off = idx * 8u;
     asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
-// 16-byte sc1 load (L1 bypass) of two adjacent granules; compiler-tracked (s_waitcnt vmcnt inserted by hipcc)
-__device__ __forceinline__ u4v ld_pair(__amdgpu_buffer_rsrc_t rs, unsigned byteoff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, byteoff, 0, 16 /* sc1 */);
+// 16-byte sc1 load (L1 bypass) of two adjacent granules; compiler-tracked (s_waitcnt vmcnt inserted by hipcc).  The per-thread
+// part of the address (tid * 16) is the VGPR offset, everything wave-uniform (region, parity, slice) goes into the SGPR offset:
+// the instruction's immediate offset has 12 bits, so slice offsets folded into the VGPR cost one register per slice.
+__device__ __forceinline__ u4v ld_pair(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16 /* sc1 */);
 }
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 // Weights parked in the accumulator half of the register file ("a" constraint = AGPR class for the value's whole life):
@@ -141,26 +143,29 @@ constexpr int M_DEAD = 0, M_TEAM = 1, M_RANK = 2;
 // All-gather of NV published vectors (R x 512 granules each, mailbox order [rq][wl][S][iu][j][e]; slice m = (rq, wl) holds
 // what wave wl of EVERY workgroup published for row quad rq).  Every load of every vector is in flight at once -- one L2
 // round trip when the producers are done, which they normally are: the shadow work of the window sits between the publish
-// and this poll -- and only slices that came back incomplete are read again.
+// and this poll.  If a slice came back incomplete, only the last slice (published by the wave that is dispatched last) is
+// polled until it is complete, then everything is fetched again: no per-slice state is kept (the per-slice retry masks
+// of the first version cost ~16 SGPR pairs and pushed the 8-row kernel into scratch spills).
+// voff = tid * 16; soff[v] = byte offset of vector v's region (wave-uniform).
 // PRE: the caller already requested every slice once (gather_issue, in the middle of the shadow work of the window, when the
 // producers are normally done): the first look then costs no round trip of its own.
 template <int NM, int NV>
-__device__ __forceinline__ void gather_issue(__amdgpu_buffer_rsrc_t rs, const unsigned (&byteoff)[NV], u4v (&g)[NV][NM]) {
+__device__ __forceinline__ void gather_issue(__amdgpu_buffer_rsrc_t rs, unsigned voff, const unsigned (&soff)[NV], u4v (&g)[NV][NM]) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, byteoff[v] + m * 4096u);
+        for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, voff, soff[v] + m * 4096u);
     __builtin_amdgcn_sched_barrier(0);
 }
 template <int NM, int NV, bool PRE = false>
-__device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, const unsigned (&byteoff)[NV], unsigned tag, u4v (&g)[NV][NM],
+__device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, unsigned voff, const unsigned (&soff)[NV], unsigned tag, u4v (&g)[NV][NM],
                                             bool &dead, unsigned *err, unsigned code) {
     if (!PRE) {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, byteoff[v] + m * 4096u);
+            for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, voff, soff[v] + m * 4096u);
     }
     unsigned spins = 0;
     for (;;) {
@@ -170,13 +175,18 @@ __device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, const uns
 #pragma unroll
             for (int m = 0; m < NM; ++m) ok = ok && g[v][m].y == tag && g[v][m].w == tag;
         if (__all(ok) || dead) break;
-        if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
-        __builtin_amdgcn_s_sleep(1);
+        // wait on the sentinel slice of the last vector, then look at everything again
+        for (;;) {
+            if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+            __builtin_amdgcn_s_sleep(1);
+            const u4v sv = ld_pair(rs, voff, soff[NV - 1] + (NM - 1) * 4096u);
+            if (__all(sv.y == tag && sv.w == tag)) break;
+        }
+        if (dead) break;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int m = 0; m < NM; ++m)
-                if (!__all(g[v][m].y == tag && g[v][m].w == tag)) g[v][m] = ld_pair(rs, byteoff[v] + m * 4096u);
+            for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, voff, soff[v] + m * 4096u);
     }
 }
 
@@ -294,6 +304,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
     const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
     // where gathered pair m = (rq, wl') of this thread goes in LDS (floats): tid = S*32 + iu*8 + j*2 + e/2
     //   -> [rq][S = tid>>5][kp = 4 wl' + iu][j][e] = ((rq*8 + S)*16 + 4 wl')*16 + 2*(tid & 31)
+    const unsigned gvoff = (unsigned)tid * 16u;   // this thread's 16 bytes inside a 4 KB slice
     auto pair_dst = [&](int m) { return (((m >> 2) * 8 + (tid >> 5)) * 16 + 4 * (m & 3)) * 16 + 2 * (tid & 31); };
 
     // ---- resident weights: batch_w [32 WG][4 waves][320][64 lanes] (A-operand images, api.hip):
@@ -473,18 +484,31 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             }
             PB(0);   // phase A + publish
             {
-                // (both vectors in flight at once would save one L2 round trip, but the 2 x NM x 4 registers of it push the
-                // kernel into scratch spills: measured with -Rpass-analysis, R = 8: 130 vs 17 registers, R = 4: 13 vs 0)
-                u4v gx[1][NM];
-                const unsigned offs[1] = {(L::G_X2 + par * L::RG) * 8u + (unsigned)tid * 16u};
-                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 21u);
-                PB(1);   // x2 arrived
+                if (NQ == 1) {
+                    // R = 4: both vectors in one round trip (2 x 4 loads in flight)
+                    u4v gx[2][NM];
+                    const unsigned offs[2] = {(L::G_X2 + par * L::RG) * 8u, (L::G_H1 + par * L::RG) * 8u};
+                    gather_vecs<NM, 2>(mrs, gvoff, offs, epoch, gx, dead, a.err, 21u);
+                    PB(1);   // x2 and h1' arrived
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
-                const unsigned offs2[1] = {(L::G_H1 + par * L::RG) * 8u + (unsigned)tid * 16u};
-                gather_vecs<NM, 1>(mrs, offs2, epoch, gx, dead, a.err, 22u);
+                    for (int m = 0; m < NM; ++m) {
+                        *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                        *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[1][m].x), __uint_as_float(gx[1][m].z));
+                    }
+                } else {
+                    // R = 8: both vectors in flight at once (2 x 8 x 4 registers) push the kernel into scratch spills (measured with
+                    // -Rpass-analysis: 59 vs 3 registers): two round trips
+                    u4v gx[1][NM];
+                    const unsigned offs[1] = {(L::G_X2 + par * L::RG) * 8u};
+                    gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 21u);
+                    PB(1);   // x2 arrived
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                    for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                    const unsigned offs2[1] = {(L::G_H1 + par * L::RG) * 8u};
+                    gather_vecs<NM, 1>(mrs, gvoff, offs2, epoch, gx, dead, a.err, 22u);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                }
             }
             PB(2);   // h1' gathered, both written
             __syncthreads();   // B1
@@ -522,16 +546,12 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 u4v gx[1][NM];
-                const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u + (unsigned)tid * 16u};
-                if (NQ == 1) {
-                    // R = 4: the x3 slices are requested half way through the shadow MFMAs (the producers are normally done by
-                    // then), so their L2 round trip runs under the second half instead of after it
-                    mfma_gates<NQ, 3, true, 0, 4>(wa, vH1, lane, acc);
-                    gather_issue<NM, 1>(mrs, offs, gx);
-                    mfma_gates<NQ, 3, true, 4, 8>(wa, vH1, lane, acc);
-                } else {
-                    mfma_gates<NQ, 3, true>(wa, vH1, lane, acc);
-                }
+                const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u};
+                // the x3 slices are requested half way through the shadow MFMAs (the producers are normally done by then), so
+                // their L2 round trip runs under the second half instead of after it
+                mfma_gates<NQ, 3, true, 0, 4>(wa, vH1, lane, acc);
+                gather_issue<NM, 1>(mrs, gvoff, offs, gx);
+                mfma_gates<NQ, 3, true, 4, 8>(wa, vH1, lane, acc);
                 PB(7);   // W_hh1 MFMAs issued
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -539,8 +559,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     if (q == 0 || my_rq == q) { gh1r = fr + cst[C_H1R * 256]; gh1z = fz + cst[C_H1Z * 256]; gh1n = fn + cst[C_H1N * 256]; }
                 }
                 PB(8);   // W_hh1 folded
-                if (NQ == 1) gather_vecs<NM, 1, true>(mrs, offs, epoch, gx, dead, a.err, 23u);
-                else gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 23u);
+                gather_vecs<NM, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 23u);
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
@@ -571,10 +590,10 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 const f4 *wnl = (const f4 *)(lds + L::L_WN) + (size_t)wl * 8 * 64 + lane;
                 u4v gx[1][NM];
-                const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u + (unsigned)tid * 16u};
+                const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u};
 #pragma unroll
                 for (int S = 0; S < 8; ++S) {
-                    if (NQ == 1 && S == 4) gather_issue<NM, 1>(mrs, offs, gx);   // R = 4: fc1 slices requested half way (see window 2)
+                    if (S == 4) gather_issue<NM, 1>(mrs, gvoff, offs, gx);   // fc1 slices requested half way (see window 2)
                     f4 b[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64 + lane] - vP[(q * 8 + S) * 64 + lane];
@@ -596,8 +615,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     if (q == 0 || my_rq == q) { gh2r = fr + cst[C_H2R * 256]; gh2z = fz + cst[C_H2Z * 256]; gh2n = fn + cst[C_H2N * 256]; }
                 }
                 PB(12);  // W_hh2
-                if (NQ == 1) gather_vecs<NM, 1, true>(mrs, offs, epoch, gx, dead, a.err, 24u);
-                else gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 24u);
+                gather_vecs<NM, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 24u);
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
@@ -622,8 +640,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             PB(16);  // noise
             {
                 u4v gx[1][NM];
-                const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u + (unsigned)tid * 16u};
-                gather_vecs<NM, 1>(mrs, offs, epoch, gx, dead, a.err, 25u);
+                const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u};
+                gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 25u);
 #pragma unroll
                 for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
             }
@@ -724,7 +742,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             if (MODE == WRNN_MODE_RAW) {
                 const unsigned tg = epoch & 0x3fffffu;
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) gqa[i] = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u + (unsigned)lane * 16u);
+                for (int i = 0; i < NQ; ++i) gqa[i] = ld_pair(mrs, (unsigned)lane * 16u, (L::G_PR + par * L::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u);
                 unsigned spins = 0;
                 for (;;) {
                     bool ok = true;
@@ -736,7 +754,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
                     for (int i = 0; i < NQ; ++i)
                         if (!__all((gqa[i].y >> 10) == tg && (gqa[i].w >> 10) == tg))
-                            gqa[i] = ld_pair(mrs, (L::G_PR + par * L::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u + (unsigned)lane * 16u);
+                            gqa[i] = ld_pair(mrs, (unsigned)lane * 16u, (L::G_PR + par * L::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u);
                 }
             }
             PB(21);  // race candidates arrived
