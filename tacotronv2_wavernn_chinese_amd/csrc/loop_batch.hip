@@ -44,6 +44,15 @@ typedef unsigned long long u64;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
+// LDS pointers with an OPAQUE per-thread base: the base (one VGPR) goes through an empty asm so that the compiler cannot fold the
+// buffer's constant LDS address into it -- every access is then "base + 16-bit immediate".  With foldable bases hipcc hoisted
+// ~50 different precomputed LDS addresses out of the step loop and kept each in its own VGPR (the constants exceed the DS
+// offset field once the buffer address is part of them): measured in the ISA, 50 distinct ds_read_b128 address registers.
+typedef const f4 __attribute__((address_space(3))) *lds_cf4p;
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef f2v __attribute__((address_space(3))) *lds_f2p;
+typedef const float __attribute__((address_space(3))) *lds_cfp;
+__device__ __forceinline__ unsigned launder(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
 namespace {
 
@@ -192,12 +201,12 @@ __device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, unsigned 
 
 // acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane]
 template <int NQ, int NG, bool AG, int S0 = 0, int S1 = 8>
-__device__ __forceinline__ void mfma_gates(const float *w, const f4 *xv, int lane, f4 (&acc)[NG][NQ]) {
+__device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc)[NG][NQ]) {
 #pragma unroll
     for (int S = S0; S < S1; ++S) {
         f4 b[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64 + lane];
+        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -210,7 +219,7 @@ __device__ __forceinline__ void mfma_gates(const float *w, const f4 *xv, int lan
 }
 // one weight row set (32 slabs at w[..]); the K sum is split over NP independent accumulator chains
 template <int NQ, int NP, bool AG>
-__device__ __forceinline__ void mfma_single(const float *w, const f4 *xv, int lane, f4 (&sum)[NQ]) {
+__device__ __forceinline__ void mfma_single(const float *w, lds_cf4p xv, f4 (&sum)[NQ]) {
     f4 acc[NP][NQ];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -220,7 +229,7 @@ __device__ __forceinline__ void mfma_single(const float *w, const f4 *xv, int la
     for (int S = 0; S < 8; ++S) {
         f4 b[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64 + lane];
+        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float wa = wget<AG>(w[4 * S + e]);
@@ -302,10 +311,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
     const bool wg_has_fc3 = 32 * g < NC;
     // mailbox index of this thread's (unit, batch row) in a gathered vector: [rq][wl][S = g>>2][iu][j][e = g&3]
     const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
-    // where gathered pair m = (rq, wl') of this thread goes in LDS (floats): tid = S*32 + iu*8 + j*2 + e/2
-    //   -> [rq][S = tid>>5][kp = 4 wl' + iu][j][e] = ((rq*8 + S)*16 + 4 wl')*16 + 2*(tid & 31)
     const unsigned gvoff = (unsigned)tid * 16u;   // this thread's 16 bytes inside a 4 KB slice
-    auto pair_dst = [&](int m) { return (((m >> 2) * 8 + (tid >> 5)) * 16 + 4 * (m & 3)) * 16 + 2 * (tid & 31); };
 
     // ---- resident weights: batch_w [32 WG][4 waves][320][64 lanes] (A-operand images, api.hip):
     //      W_ih2 r,z,n [0,96) -> VGPRs (the serial chain) | W_hh1 r,z,n [96,192) | W_hh2 r,z [192,256) | fc1 [256,288) |
@@ -333,11 +339,18 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
         cs[C_H1R * 256] = a.w[a.off.r1_bhh + unit]; cs[C_H1Z * 256] = a.w[a.off.r1_bhh + 512 + unit]; cs[C_H1N * 256] = a.w[a.off.r1_bhh + 1024 + unit];
         cs[C_H2R * 256] = a.w[a.off.r2_bhh + unit]; cs[C_H2Z * 256] = a.w[a.off.r2_bhh + 512 + unit]; cs[C_H2N * 256] = a.w[a.off.r2_bhh + 1024 + unit];
     }
-    const float *cst = lds + L::L_CST + tid;
     __syncthreads();
-
-    const f4 *vP = (const f4 *)(lds + L::L_P), *vQ = (const f4 *)(lds + L::L_Q);
-    const f4 *vH1 = (const f4 *)(lds + L::L_H1);
+    // opaque per-thread LDS bases (see lds_cf4p): activation vectors as B operands (P | Q | H1 are contiguous), the LDS-resident
+    // A operands, the constants, the destination of gathered pairs
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const lds_cf4p vP = (lds_cf4p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + (unsigned)lane * 16u);
+    const lds_cf4p vQ = vP + L::VEC / 4, vH1 = vP + 2 * (L::VEC / 4);
+    const lds_cf4p w3 = (lds_cf4p)(size_t)launder(smem_base + (unsigned)L::L_FC3 * 4u + ((unsigned)(wl * 2) * 8u * 64u + (unsigned)lane) * 16u);
+    const lds_cf4p wnl = (lds_cf4p)(size_t)launder(smem_base + (unsigned)L::L_WN * 4u + ((unsigned)wl * 8u * 64u + (unsigned)lane) * 16u);
+    const lds_cfp cst = (lds_cfp)(size_t)launder(smem_base + (unsigned)L::L_CST * 4u + (unsigned)tid * 4u);
+    // gathered pair m = (rq, wl') of this thread: tid = S*32 + iu*8 + j*2 + e/2 -> [rq][S = tid>>5][kp = 4 wl' + iu][j][e], i.e. float
+    // index ((rq*8 + S)*16 + 4 wl')*16 + 2*(tid & 31) = thread part + (m>>2)*2048 + (m&3)*64
+    const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tid >> 5) * 256u + 2u * (unsigned)(tid & 31)) * 4u);
 
     bool dead = false;
     unsigned epoch = 0;
@@ -368,26 +381,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
         }
 
         // conditioning {cI, v_r, v_z, v_n} of step ts for (unit, row): record + 5-tap upsampling (prologue.hip)
-        auto prep_cond = [&](int64_t ts) {
-            const int64_t pos = rw.start + ts;
-            const bool live = pos < a.total_len;           // fold padding 'after' = zero rows (:327-330)
-            const int fi = live ? nfi : T;                 // T = the all-zero conditioning record
-            const int ph = live ? nph : 0;
-            if (++nph == HOP) { nph = 0; ++nfi; }
-            pend_frame = fi;
-            const float4 *r = (const float4 *)(recb + (size_t)fi * 512 * 32);
-            const float4 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4], a5 = r[5];
-            const float *kt = ktab + ph * 5;
-            const float k0 = kt[0], k1 = kt[1], k2 = kt[2], k3 = kt[3], k4 = kt[4];
-            cd.x = fmaf(k4, a2.x, fmaf(k3, a1.w, fmaf(k2, a1.z, fmaf(k1, a1.y, fmaf(k0, a1.x, a0.x)))));
-            cd.y = fmaf(k4, a5.y, fmaf(k3, a4.z, fmaf(k2, a3.w, fmaf(k1, a3.x, fmaf(k0, a2.y, a0.y)))));
-            cd.z = fmaf(k4, a5.z, fmaf(k3, a4.w, fmaf(k2, a4.x, fmaf(k1, a3.y, fmaf(k0, a2.z, a0.z)))));
-            cd.w = fmaf(k4, a5.w, fmaf(k3, a5.x, fmaf(k2, a4.y, fmaf(k1, a3.z, fmaf(k0, a2.w, a0.w)))));
-        };
-        // R = 4 only (the 8-row kernel has no registers to spare): the same conditioning with its loads issued one step ahead.
-        // The record (24 floats) stays in registers and is re-read only when the frame changes, the 5 taps of step t + 2 are
-        // requested while the values of step t + 1 are combined, so no load latency is waited for (measured: 2 150 cycles per
-        // step when the loads are waited for where they are issued).
+        // The loads are issued one step ahead: the record (24 floats) stays in registers and is re-read only when the frame
+        // changes, the 5 taps of step t + 2 are requested while the values of step t + 1 are combined, so no load latency is
+        // waited for (measured: 2 150 - 2 400 cycles per step when the loads are waited for where they are issued).
         float4 ra0, ra1, ra2, ra3, ra4, ra5;
         float rk0 = 0.f, rk1 = 0.f, rk2 = 0.f, rk3 = 0.f, rk4 = 0.f;
         ra0 = ra1 = ra2 = ra3 = ra4 = ra5 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -452,13 +448,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 } else { nz0 = pz0; nz1 = pz1; }
             } else { nz0 = 0.f; nz1 = 0.f; }
         };
-        if (NQ == 1) {
-            cond_fetch(0);
-            cond_combine();
-            if (a.steps > 1) cond_fetch(1);
-        } else {
-            prep_cond(0);
-        }
+        cond_fetch(0);
+        cond_combine();
+        if (a.steps > 1) cond_fetch(1);
         __syncthreads();
 
         for (int64_t t = 0; t < a.steps; ++t) {
@@ -492,8 +484,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     PB(1);   // x2 and h1' arrived
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
-                        *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
-                        *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[1][m].x), __uint_as_float(gx[1][m].z));
+                        gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                        gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[1][m].x), __uint_as_float(gx[1][m].z)};
                     }
                 } else {
                     // R = 8: both vectors in flight at once (2 x 8 x 4 registers) push the kernel into scratch spills (measured with
@@ -503,11 +495,11 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 21u);
                     PB(1);   // x2 arrived
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                    for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
                     const unsigned offs2[1] = {(L::G_H1 + par * L::RG) * 8u};
                     gather_vecs<NM, 1>(mrs, gvoff, offs2, epoch, gx, dead, a.err, 22u);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
                 }
             }
             PB(2);   // h1' gathered, both written
@@ -521,7 +513,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                mfma_gates<NQ, 3, false>(wv, vP, lane, acc);
+                mfma_gates<NQ, 3, false>(wv, vP, acc);
                 PB(4);   // phase B MFMAs issued
                 float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -549,9 +541,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u};
                 // the x3 slices are requested half way through the shadow MFMAs (the producers are normally done by then), so
                 // their L2 round trip runs under the second half instead of after it
-                mfma_gates<NQ, 3, true, 0, 4>(wa, vH1, lane, acc);
+                mfma_gates<NQ, 3, true, 0, 4>(wa, vH1, acc);
                 gather_issue<NM, 1>(mrs, gvoff, offs, gx);
-                mfma_gates<NQ, 3, true, 4, 8>(wa, vH1, lane, acc);
+                mfma_gates<NQ, 3, true, 4, 8>(wa, vH1, acc);
                 PB(7);   // W_hh1 MFMAs issued
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -561,7 +553,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 PB(8);   // W_hh1 folded
                 gather_vecs<NM, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 23u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_Q + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                for (int m = 0; m < NM; ++m) gdst[(1 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
             }
             PB(9);   // x3 gathered
             __syncthreads();   // B2
@@ -570,7 +562,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 3: phase C (fc1, :217-218) | gh2' = W_hh2 . h2' | gather fc1 outputs =================
             {
                 f4 sum[NQ];
-                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 160, vQ, lane, sum);
+                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 160, vQ, sum);
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -588,7 +580,6 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                const f4 *wnl = (const f4 *)(lds + L::L_WN) + (size_t)wl * 8 * 64 + lane;
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u};
 #pragma unroll
@@ -596,7 +587,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     if (S == 4) gather_issue<NM, 1>(mrs, gvoff, offs, gx);   // fc1 slices requested half way (see window 2)
                     f4 b[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64 + lane] - vP[(q * 8 + S) * 64 + lane];
+                    for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64] - vP[(q * 8 + S) * 64];
                     const f4 wn = wnl[S * 64];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -617,7 +608,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 PB(12);  // W_hh2
                 gather_vecs<NM, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 24u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_H1 + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
             }
             PB(13);  // f1 gathered
             __syncthreads();   // B3
@@ -626,7 +617,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 4: phase D (fc2, :220-221) | noise of this step, conditioning of the next | gather fc2 =================
             {
                 f4 sum[NQ];
-                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 192, vH1, lane, sum);
+                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 192, vH1, sum);
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -643,7 +634,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u};
                 gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 25u);
 #pragma unroll
-                for (int m = 0; m < NM; ++m) *(float2 *)(lds + L::L_P + pair_dst(m)) = make_float2(__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z));
+                for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
             }
             PB(18);  // f2 gathered
             __syncthreads();   // B4
@@ -652,13 +643,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 5: conditioning of the next step | phase E (fc3 :223 + sampler :225-237) | race =================
             // (the record loads are issued here, a whole window after the last publish: a wait on them directly behind a
             // granule store also waits for that store's acknowledgement -- stores count in vmcnt on gfx9 -- measured 2 281 cycles)
-            if (NQ == 1) {
-                if (t + 1 < a.steps) {
-                    cond_combine();                            // step t + 1 from what was requested a step ago
-                    if (t + 2 < a.steps) cond_fetch(t + 2);    // lands during the next step
-                }
-            } else if (t + 1 < a.steps) {
-                prep_cond(t + 1);
+            if (t + 1 < a.steps) {
+                cond_combine();                            // step t + 1 from what was requested a step ago
+                if (t + 2 < a.steps) cond_fetch(t + 2);    // lands during the next step
             }
             PB(17);  // conditioning of the next step
             {
@@ -672,12 +659,11 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                         for (int p = 0; p < NP; ++p)
 #pragma unroll
                             for (int q = 0; q < NQ; ++q) acc[st][p][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                    const f4 *w3 = (const f4 *)(lds + L::L_FC3) + (size_t)(wl * 2) * 8 * 64 + lane;
 #pragma unroll
                     for (int S = 0; S < 8; ++S) {
                         f4 b[NQ];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) b[q] = vP[(q * 8 + S) * 64 + lane];
+                        for (int q = 0; q < NQ; ++q) b[q] = vP[(q * 8 + S) * 64];
                         const f4 wa = w3[S * 64], wb = w3[(8 + S) * 64];
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
