@@ -199,14 +199,32 @@ __device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, unsigned 
     }
 }
 
-// acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane]
-template <int NQ, int NG, bool AG, int S0 = 0, int S1 = 8>
-__device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc)[NG][NQ]) {
+// The MFMA loops below are software pipelined by hand: the LDS operands of slab S + D are requested before the MFMAs of slab S
+// are issued, and scheduling barriers on either side of the MFMA group keep hipcc from sinking the reads next to their first
+// use (which it does otherwise: `ds_read x2, s_waitcnt, 24 MFMAs` per slab exposes one LDS round trip per slab, 8 per phase --
+// measured 2 092 cycles for the 192 MFMAs of phase B against the 1 555 the MFMA pipe needs).
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+
+// acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane];
+// mid() runs before slab 4 (the early request of the next exchange's granules)
+template <int NQ, int NG, bool AG, int D, class F>
+__device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc)[NG][NQ], F mid) {
+    f4 ring[D][NQ];
 #pragma unroll
-    for (int S = S0; S < S1; ++S) {
+    for (int dd = 0; dd < D; ++dd)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ring[dd][q] = xv[(q * 8 + dd) * 64];
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+        if (S == 4) mid();
         f4 b[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64];
+        for (int q = 0; q < NQ; ++q) b[q] = ring[S % D][q];
+        if (S + D < 8) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) ring[S % D][q] = xv[(q * 8 + S + D) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -215,27 +233,39 @@ __device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[gt][q] = mfma4(wa, b[q][e], acc[gt][q]);
             }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // one weight row set (32 slabs at w[..]); the K sum is split over NP independent accumulator chains
-template <int NQ, int NP, bool AG>
+template <int NQ, int NP, bool AG, int D>
 __device__ __forceinline__ void mfma_single(const float *w, lds_cf4p xv, f4 (&sum)[NQ]) {
     f4 acc[NP][NQ];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[p][q] = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 ring[D][NQ];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ring[dd][q] = xv[(q * 8 + dd) * 64];
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
         f4 b[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = xv[(q * 8 + S) * 64];
+        for (int q = 0; q < NQ; ++q) b[q] = ring[S % D][q];
+        if (S + D < 8) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) ring[S % D][q] = xv[(q * 8 + S + D) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float wa = wget<AG>(w[4 * S + e]);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[e % NP][q] = mfma4(wa, b[q][e], acc[e % NP][q]);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -264,6 +294,7 @@ template <int MODE, int NQ, bool PROF>
 __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a) {
     typedef Lay<NQ> L;
     constexpr int R = L::R, NM = L::NM;
+    constexpr int DG = NQ == 1 ? 2 : 1, DS = NQ == 1 ? 4 : 2, D3 = NQ == 1 ? 2 : 1;   // prefetch depths (slabs) of the MFMA loops
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
     int *misc_i = (int *)(lds + L::L_MISC);
@@ -513,7 +544,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                mfma_gates<NQ, 3, false>(wv, vP, acc);
+                mfma_gates<NQ, 3, false, DG>(wv, vP, acc, NoMid());
                 PB(4);   // phase B MFMAs issued
                 float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -541,9 +572,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u};
                 // the x3 slices are requested half way through the shadow MFMAs (the producers are normally done by then), so
                 // their L2 round trip runs under the second half instead of after it
-                mfma_gates<NQ, 3, true, 0, 4>(wa, vH1, acc);
-                gather_issue<NM, 1>(mrs, gvoff, offs, gx);
-                mfma_gates<NQ, 3, true, 4, 8>(wa, vH1, acc);
+                mfma_gates<NQ, 3, true, DG>(wa, vH1, acc, [&]() { gather_issue<NM, 1>(mrs, gvoff, offs, gx); });
                 PB(7);   // W_hh1 MFMAs issued
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -562,7 +591,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 3: phase C (fc1, :217-218) | gh2' = W_hh2 . h2' | gather fc1 outputs =================
             {
                 f4 sum[NQ];
-                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 160, vQ, sum);
+                mfma_single<NQ, (NQ == 1 ? 4 : 2), true, DS>(wa + 160, vQ, sum);
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -582,13 +611,25 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u};
+                // software pipeline: the LDS operands of slab S + 1 (x3, x2, gate-n weights) are requested before the MFMAs of slab S
+                // are issued (the scheduling barrier keeps hipcc from sinking the reads next to their use, which exposes the LDS
+                // latency once per slab: measured 3 900 cycles for this phase against 2 340 for W_hh1)
+                f4 xq[NQ], xp[NQ], wn = wnl[0];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
 #pragma unroll
                 for (int S = 0; S < 8; ++S) {
                     if (S == 4) gather_issue<NM, 1>(mrs, gvoff, offs, gx);   // fc1 slices requested half way (see window 2)
                     f4 b[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) b[q] = vQ[(q * 8 + S) * 64] - vP[(q * 8 + S) * 64];
-                    const f4 wn = wnl[S * 64];
+                    for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
+                    const f4 wcur = wn;
+                    if (S < 7) {
+                        wn = wnl[(S + 1) * 64];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8 + S + 1) * 64]; xp[q] = vP[(q * 8 + S + 1) * 64]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float wr = aget(wa[96 + 4 * S + e]), wz = aget(wa[128 + 4 * S + e]);
@@ -596,9 +637,10 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                         for (int q = 0; q < NQ; ++q) {
                             acc[0][q] = mfma4(wr, b[q][e], acc[0][q]);
                             acc[1][q] = mfma4(wz, b[q][e], acc[1][q]);
-                            acc[2][q] = mfma4(wn[e], b[q][e], acc[2][q]);
+                            acc[2][q] = mfma4(wcur[e], b[q][e], acc[2][q]);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -617,7 +659,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 4: phase D (fc2, :220-221) | noise of this step, conditioning of the next | gather fc2 =================
             {
                 f4 sum[NQ];
-                mfma_single<NQ, (NQ == 1 ? 4 : 2), true>(wa + 192, vH1, sum);
+                mfma_single<NQ, (NQ == 1 ? 4 : 2), true, DS>(wa + 192, vH1, sum);
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -659,12 +701,25 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                         for (int p = 0; p < NP; ++p)
 #pragma unroll
                             for (int q = 0; q < NQ; ++q) acc[st][p][q] = (f4){0.f, 0.f, 0.f, 0.f};
+                    f4 ring[D3][NQ], rwa[D3], rwb[D3];
+#pragma unroll
+                    for (int dd = 0; dd < D3; ++dd) {
+                        rwa[dd] = w3[dd * 64]; rwb[dd] = w3[(8 + dd) * 64];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) ring[dd][q] = vP[(q * 8 + dd) * 64];
+                    }
 #pragma unroll
                     for (int S = 0; S < 8; ++S) {
                         f4 b[NQ];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) b[q] = vP[(q * 8 + S) * 64];
-                        const f4 wa = w3[S * 64], wb = w3[(8 + S) * 64];
+                        for (int q = 0; q < NQ; ++q) b[q] = ring[S % D3][q];
+                        const f4 wa = rwa[S % D3], wb = rwb[S % D3];
+                        if (S + D3 < 8) {
+                            rwa[S % D3] = w3[(S + D3) * 64]; rwb[S % D3] = w3[(8 + S + D3) * 64];
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) ring[S % D3][q] = vP[(q * 8 + S + D3) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -672,6 +727,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                                 acc[0][e % NP][q] = mfma4(wa[e], b[q][e], acc[0][e % NP][q]);
                                 acc[1][e % NP][q] = mfma4(wb[e], b[q][e], acc[1][e % NP][q]);
                             }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
