@@ -59,8 +59,8 @@ CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
 # HBM bytes of the loop kernel per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md + WRITE_SIZE), keyed by (config, kernel); absent = not measured
 TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_462_885 + 1_913_781,            # profiles/r02_rocprofv3_summary.txt: fetch_c1 + write_c1, per segment launch
-                            (2, 4): 1_798_730_368 + 3_854_286_816,     # fetch_c2 + write_c2: the one launch of 64 x 110 275 samples
-                            (3, 4): 1_798_730_368 + 3_854_286_816}
+                            (2, 4): 1_795_037_056 + 60_130_080,        # session L (shipped kernel) fetch_c2 + write_c2: the one launch of
+                            (3, 4): 1_795_037_056 + 60_130_080}        # 64 x 110 275 samples (3.85 GB of writes before: scratch spills)
 
 
 def cpu_baseline(frames: int = 200, max_threads: int = 16) -> dict:
