@@ -539,6 +539,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             ba.noise_mode = a.noise_mode; ba.seed = a.seed; ba.noise1 = a.noise1; ba.noise2 = a.noise2; ba.x_forced = a.x_forced; ba.x_init = a.x_init;
             ba.logits_out = a.logits_out; ba.labels_out = a.labels_out; ba.samples_out = a.samples_out;
             ba.mail = h->mail; ba.ctl = h->ctl; ba.err = h->err_dev; ba.prof = h->prof;
+            if (const char *e = getenv("WRNN_BATCH_PP")) ba.variant = atoi(e) & 1;   // developer knob: ping-pong schedule of the 8-row kernel (loop_batch.hip), off until measured
             HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
             HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
             if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long), s));

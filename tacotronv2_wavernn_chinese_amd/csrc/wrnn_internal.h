@@ -216,6 +216,7 @@ struct WrnnBatchArgs {
     unsigned *ctl;
     unsigned *err;
     unsigned long long *prof;
+    int32_t variant;          // bit 0: ping-pong schedule of the 8-row kernel (WRNN_BATCH_PP=1; opt-in until measured)
 };
 
 // kernels / launchers (defined in the .hip files)

@@ -14,7 +14,8 @@ import tempfile
 SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tacotronv2_wavernn_chinese_amd', 'csrc', 'loop_batch.hip')
 HIPCC = '/opt/rocm/bin/hipcc'
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17']
-NAMES = {'ILi0ELi2ELb0': 'RAW_R8', 'ILi0ELi1ELb0': 'RAW_R4', 'ILi1ELi2ELb0': 'MOL_R8', 'ILi1ELi1ELb0': 'MOL_R4'}
+NAMES = {'ILi0ELi2ELb0ELb0': 'RAW_R8', 'ILi0ELi1ELb0ELb0': 'RAW_R4', 'ILi1ELi2ELb0ELb0': 'MOL_R8', 'ILi1ELi1ELb0ELb0': 'MOL_R4',
+         'ILi0ELi2ELb0ELb1': 'RAW_R8_pingpong (opt-in variant)'}
 
 
 def main() -> int:
@@ -27,7 +28,7 @@ def main() -> int:
             return 1
         print('# Static census of loop_batch_kernel as committed (hipcc -O3 --offload-arch=gfx950, ROCm 7.2; tools/static_census.py):')
         print('# -Rpass-analysis=kernel-resource-usage and, per barrier window of the generated ISA, instruction counts by class.')
-        print('# Template arguments: <MODE (0 RAW, 1 MOL), NQ (row quads per team: 1 = 4 rows, 2 = 8 rows), PROF>.\n')
+        print('# Template arguments: <MODE (0 RAW, 1 MOL), NQ (row quads per team: 1 = 4 rows, 2 = 8 rows), PROF, PP (ping-pong schedule: opt-in)>.\n')
         cur = None
         for line in r.stderr.splitlines():
             m = re.search(r'remark: (.*?)\s*\[-Rpass', line)
@@ -37,7 +38,7 @@ def main() -> int:
             if t.startswith('Function Name:'):
                 if cur:
                     print(' \t'.join(cur))
-                cur = [t.split(':', 1)[1].strip()] if 'Lb0' in t else None
+                cur = [t.split(':', 1)[1].strip()] if 'Lb0ELb' in t else None
             elif cur is not None and re.match(r'(TotalSGPRs|VGPRs|AGPRs|ScratchSize|Occupancy|SGPRs Spill|VGPRs Spill)', t):
                 cur.append(t)
         if cur:
