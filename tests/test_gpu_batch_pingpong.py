@@ -2,7 +2,7 @@
 
 The variant was written at the end of round 2 after the round's GPU budget was spent, so it has not run on hardware yet;
 it is not selected by default (the shipped kernels are ISA-identical with and without it in the source) and these tests
-only run with `WRNN_TEST_PP=1`.  Every loop of the variant adds in the order of the lock-step 8-row loops, so the contract
+only run with `WRNN_TEST_NEXT=1`.  Every loop of the variant adds in the order of the lock-step 8-row loops, so the contract
 is bit-equality with the lock-step kernel -- labels AND fed-back samples -- on top of parity with the reference golden.
 """
 import os
@@ -14,7 +14,7 @@ import torch
 from tests.golden_util import load_case
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('WRNN_TEST_PP') != '1', reason='experimental schedule: set WRNN_TEST_PP=1')]
+              pytest.mark.skipif(os.environ.get('WRNN_TEST_NEXT') != '1', reason='written after the round\'s GPU budget was spent: set WRNN_TEST_NEXT=1')]
 
 
 def _model(sd, mode='RAW', bits=10):
@@ -89,3 +89,23 @@ def test_pingpong_equals_lockstep_mol():
     mels = make_mels(9, 16, 30)
     (la, sa), (lb, sb) = _both(m, mels, noise_mode=_cabi.NOISE_PHILOX, seed=77)
     np.testing.assert_array_equal(sb, sa)
+
+
+@pytest.mark.parametrize('rpb', [2, 8])
+def test_a_team_runs_several_batches_back_to_back(rpb):
+    """19 rows with 2 (resp. 8) rows per batch: 10 batches over 8 teams (teams 0 and 1 run two batches one after the other:
+    state re-initialised, tags keep counting) resp. 3 batches of 8 + 8 + 3 rows on the 8-row kernel.  Greedy sampling, 3 distinct
+    mels in rotation: rows with the same mel must agree whatever batch / team / slot ran them, in both schedules."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
+    sd = make_state_dict(0, mode='RAW', variant='peaky')
+    m = _model(sd)
+    base = make_mels(77, 3, 21)
+    mels = np.stack([base[i % 3] for i in range(19)])
+    for pp in ((0, 1) if rpb == 8 else (0,)):
+        with _env(WRNN_BATCH_ROWS=rpb, WRNN_BATCH_PP=pp):
+            lab = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_ARGMAX)['labels'].cpu().numpy()
+        assert lab.shape == (19, 21 * 275)
+        for i in range(3, 19):
+            np.testing.assert_array_equal(lab[i], lab[i % 3])
+        assert not np.array_equal(lab[0], lab[1])

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 rm -f gpurun_out/pp_*
-WRNN_TEST_PP=1 timeout 300 python -m pytest tests/test_gpu_batch_pingpong.py -x -q > gpurun_out/pp_pytest.log 2>&1
+WRNN_TEST_NEXT=1 timeout 300 python -m pytest tests/test_gpu_batch_pingpong.py -x -q > gpurun_out/pp_pytest.log 2>&1
 echo "rc pytest_pp $?" >> gpurun_out/pp_summary.log
 for pp in 0 1; do
   WRNN_BATCH_PP=$pp WRNN_TEAM_PROF=1 timeout 120 python bench.py --config 2 --frames 41 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/pp_prof_c2_pp$pp.err
