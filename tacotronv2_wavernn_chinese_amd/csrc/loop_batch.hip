@@ -522,8 +522,12 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     const u2v so = __builtin_amdgcn_permlane32_swap(__float_as_uint(give_o), __float_as_uint(give_o), false, false);
                     const float recv_e = __uint_as_float(upper ? se.x : se.y), recv_o = __uint_as_float(upper ? so.x : so.y);
                     nz0 = upper ? recv_e : mine_e; nz1 = upper ? mine_e : recv_e;
-                    pz0 = upper ? recv_o : mine_o; pz1 = upper ? mine_o : recv_o;
-                } else { nz0 = pz0; nz1 = pz1; }
+                    if constexpr (PP) {   // the odd step's pair waits in AGPRs (the lock-step kernel keeps it in 8 bytes of scratch)
+                        apark(pz0, upper ? recv_o : mine_o); apark(pz1, upper ? mine_o : recv_o);
+                    } else {
+                        pz0 = upper ? recv_o : mine_o; pz1 = upper ? mine_o : recv_o;
+                    }
+                } else { nz0 = aget(pz0); nz1 = aget(pz1); }
             } else { nz0 = 0.f; nz1 = 0.f; }
         };
         cond_fetch(0);
