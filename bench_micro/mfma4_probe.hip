@@ -4,7 +4,9 @@
 //  (2) exactness: a K-chain of MFMAs against an fmaf chain in the same order (bitwise);
 //  (3) issue rate: cycles per MFMA for 1 / 2 waves per SIMD with NCH independent accumulator chains,
 //      with the B operand held in registers and with the B operand read from LDS (ds_read_b128 per 4 MFMAs);
-//  (4) the kp reduction used after the K loop: 2 x permlane32_swap + 1 x permlane16_swap + 2 row_ror DPP adds.
+//  (4) the kp reduction used after the K loop: 2 x permlane32_swap + 1 x permlane16_swap + 2 row_ror DPP adds;
+//  (5) co-issue: NV independent v_fma_f32 (and one DPP add) of the SAME wave behind every MFMA -- does VALU work (the folds of the
+//      previous phase, gates, noise) hide under the matrix pipe, or does it add to the 8 cycles per MFMA?
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -73,6 +75,49 @@ __global__ void reduce_kernel(const float *in, float *out) {
     out[l] = t;
 }
 
+
+// (5) one wave per SIMD, 3 accumulator chains, B from registers; after every MFMA: NV v_fma_f32 on independent registers and
+// (DPP) one row_ror DPP add; scheduling barriers pin the order
+template <int NV, bool DPP>
+__global__ void __launch_bounds__(256) mix_kernel(float *o, unsigned long long *cyc, int iters) {
+    f4 acc[3];
+    float w[32], x[8];
+    for (int i = 0; i < 32; ++i) w[i] = o[threadIdx.x + i];
+    for (int i = 0; i < 8; ++i) x[i] = o[threadIdx.x + 40 + i];
+    float dp = o[threadIdx.x + 50];
+    const float k1 = o[threadIdx.x + 51], k2 = o[threadIdx.x + 52];
+    for (int c = 0; c < 3; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[s], w[(s + 1 + c) & 31], acc[c], 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[v]) : "v"(k1), "v"(k2));
+                if (DPP) asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(dp));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float sacc = dp;
+    for (int c = 0; c < 3; ++c) sacc += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    for (int i = 0; i < 8; ++i) sacc += x[i];
+    o[threadIdx.x] = sacc;
+    if (lane == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+template <int NV, bool DPP>
+void mix(float *d, unsigned long long *c) {
+    const int iters = 500;
+    hipLaunchKernelGGL((mix_kernel<NV, DPP>), dim3(1), dim3(256), 0, 0, d, c, iters);
+    unsigned long long h[8];
+    hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
+    printf("co-issue: MFMA + %d v_fma_f32%s behind each: %.2f cycles per MFMA (wave 0)\n", NV, DPP ? " + 1 DPP add" : "", (double)h[0] / (iters * 96.0));
+}
+
 template <int NCH, bool LDSB>
 void rate(const char *name, float *d, unsigned long long *c) {
     const int iters = 500;
@@ -133,5 +178,6 @@ int main() {
     rate<6, false>("4x4x1_16b, 6 chains, B in regs", d, c);
     rate<2, true>("4x4x1_16b, 2 chains, B from LDS", d, c);
     rate<6, true>("4x4x1_16b, 6 chains, B from LDS", d, c);
+    mix<0, false>(d, c); mix<1, false>(d, c); mix<2, false>(d, c); mix<3, false>(d, c); mix<4, false>(d, c); mix<2, true>(d, c);
     return 0;
 }
