@@ -1,4 +1,4 @@
-// Building blocks shared by the batch kernels (loop_batch.hip, loop_batch_cs.hip): team / mailbox primitives, the
+// Building blocks of the batch kernel (loop_batch.hip; kept apart so that experimental schedules can share them): team / mailbox primitives, the
 // v_mfma_f32_4x4x1 loops with hand-made software pipelining, the K-phase fold, the LDS carve-up.  See loop_batch.hip for the
 // mapping these pieces implement.
 #pragma once
