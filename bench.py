@@ -3,7 +3,7 @@
     python bench.py --gpus N --steps K --warmup W [--config {1,2,4,3}]
 
 `python bench.py --gpus N` launches its own N ranks (re-exec under torch.distributed.run, one rank per GPU, RCCL);
-started under torch.distributed.run it uses the ranks it is given.
+started under torch.distributed.run it uses the ranks it is given (`--gpus` then defaults to WORLD_SIZE).
 
 One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
   --config 1 (default; BASELINE.json configs[1], the config the metric is quoted on): ONE ~5 s utterance per GPU,
@@ -13,16 +13,27 @@ One "step" = one pass of the hot path over one batch of synthetic input resident
              on the matrix cores);
   --config 4 (configs[4]): MOL 9-bit, 32 utterances per GPU (batch kernel, 4 rows per team);
   --config 3 (configs[3]): throughput mode, 64 utterances per GPU (512 over 8 GPUs): rank 0 owns all clips, scatters the
-             mels over RCCL, every rank generates its 64, the samples are gathered back on rank 0 -- the only collectives
-             of the path (utterances are independent: SURVEY.md 8e); scatter + gather are inside the timed region.
+             mels over RCCL, every rank generates its 64, the waveforms are gathered back on rank 0 -- the only collectives
+             of the path (utterances are independent: SURVEY.md 8e); scatter + gather are inside the timed region.  The
+             process group is ALWAYS initialised for this config, also at N=1 (a one-rank RCCL communicator): the scatter /
+             gather calls are the same code at every N.
 metric = audio ksamples/s (all loop steps of all rows counted, like the reference's own "Gen Rate" meter,
 fatchord_version.py:267-271), whole job over all N GPUs; weak scaling (the per-GPU batch is fixed).
+
+The headline fields are the selected config's.  The default run (config 1, N=1) additionally times configs[2] and [4] for a
+few steps and attaches them as `extra_configs` {"2": {...}, "4": {...}} to the same JSON line (~10 s).
 
 Extra objects on the JSON line:
   roofline      -- ALGORITHMIC bytes (weights once per step for the whole batch + 836 B conditioning/sample, SURVEY.md
                    8d) or FLOPs (8 668 160 per sample RAW) x steps per launch / the loop kernel's average launch duration
                    (HIP events recorded by the library on the launch stream), against the bound SURVEY 8d names for the
-                   batch size: HBM 8 TB/s for B=1 and MOL B=32, the fp32 matrix/vector peak 157.3 TFLOP/s for B=64.
+                   batch size: HBM for B=1 and MOL B=32 (`peak` = the 8 TB/s of the data sheet, `peak_measured` = a
+                   device-to-device copy timed in this run, read + write bytes), the fp32 matrix/vector peak 157.3 TFLOP/s
+                   for B=64.  `traffic` = measured HBM bytes per launch from the PMC passes under profiles/ (a static
+                   number from that profile, not from this run: `traffic_source` says which file).  For B=1 the weights are
+                   register/LDS resident and HBM is idle: the bound that actually binds is the exchange latency,
+                   `latency_model` = {exchanges per step, all-gather round time of the 32 workgroups of one XCD measured by
+                   bench_micro/handoff, floor_us} and `frac_of_latency_floor` = floor / measured us per step.
   cpu_baseline  -- the CPU restatement (oracle/, "port") timed on this box's host cores on BASELINE configs[0]'s clip
                    (80x200, 55 000 steps), rank 0 at N=1 only;
   cpu_reference -- the UNMODIFIED reference generate() (PyTorch CPU) timed by oracle/time_reference.py where
@@ -57,10 +68,17 @@ CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
            4: dict(mode='MOL', bits=9, batch=32, name='configs[4]'),
            3: dict(mode='RAW', bits=10, batch=64, name='configs[3]')}
 # HBM bytes of the loop kernel per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
-# correction of MI355X_MICROARCH.md + WRITE_SIZE), keyed by (config, kernel); absent = not measured
-TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_462_885 + 1_913_781,            # profiles/r02_rocprofv3_summary.txt: fetch_c1 + write_c1, per segment launch
-                            (2, 4): 1_795_037_056 + 60_130_080,        # session L (shipped kernel) fetch_c2 + write_c2: the one launch of
-                            (3, 4): 1_795_037_056 + 60_130_080}        # 64 x 110 275 samples (3.85 GB of writes before: scratch spills)
+# correction of MI355X_MICROARCH.md + WRITE_SIZE), keyed by (config, kernel); absent = not measured.  STATIC numbers.
+TRAFFIC_SOURCE = 'profiles/r02_rocprofv3_summary.txt (static: PMC passes of round 2 on the same kernels, not this run)'
+TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_462_885 + 1_913_781,            # fetch_c1 + write_c1, per segment launch
+                            (2, 4): 1_795_037_056 + 60_130_080,        # fetch_c2 + write_c2: the one launch of 64 x 110 275 samples
+                            (3, 4): 1_795_037_056 + 60_130_080}
+# What bounds the B=1 latency kernel: 4 dependent all-gathers among the 32 workgroups of one XCD per step.
+# bench_micro/handoff.hip measures one such round (512 granules published, polled with sc1 loads, written to LDS, 2
+# barriers, NO compute between rounds): profiles/r03_handoff_microbench.txt.
+LATENCY_MODEL = dict(exchanges_per_step=4, barriers_per_step=5, allgather_round_us=0.746, raw_hop_us=0.27,
+                     source='profiles/r03_handoff_microbench.txt (gather st=plain ld=sc1 team=32: 0.746-0.768 us per round; '
+                            'raw one-way hop profiles/r01_handoff_microbench.txt)')
 
 
 def cpu_baseline(frames: int = 200, max_threads: int = 16) -> dict:
@@ -106,6 +124,28 @@ def cpu_reference() -> dict | None:
     return out
 
 
+def measure_copy_peak(dev, nbytes: int = 1 << 30, reps: int = 8) -> float | None:
+    """Device-to-device copy of `nbytes` timed with HIP events on the current stream: (read + write) bytes / s.  SURVEY 8d:
+    "replace nominal with a measured device-copy peak on the box".  bench_micro/devcopy.hip is the hand-written version."""
+    import torch
+    try:
+        src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        del src, dst
+        return 2.0 * nbytes / (ms * 1e-3)
+    except Exception:   # the peak is an annotation: never sink the bench line for it
+        return None
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` with no ranks around it: become the launcher."""
     with socket.socket() as s:
@@ -118,54 +158,19 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
-    ap.add_argument('--frames', type=int, default=T_FRAMES)
-    ap.add_argument('--batch', type=int, default=0, help='rows per GPU (default: the config\'s)')
-    ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'batch', 'simple'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-dry-run', action='store_true',
-                    help='exercise the launcher / rendezvous / collectives / timing / JSON scaffolding on CPU (gloo) with a stand-in for the '
-                         'device calls: tests only, the line it prints is not a measurement')
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and 'RANK' not in os.environ:
-        return self_launch(args)
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
-        return 2
-
+def run_config(cfg_id: int, *, world: int, rank: int, dev, dry: bool, steps: int, warmup: int, frames: int, batch: int,
+               kernel_name: str, copy_peak: float | None, dump: str | None = None, phase_profile: bool = False) -> dict | None:
+    """Time `steps` passes of config `cfg_id` (after `warmup` untimed ones) and return the fields of its JSON line (rank 0;
+    None elsewhere)."""
     import torch
     import torch.distributed as dist
     from tacotronv2_wavernn_chinese_amd import _cabi
     from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_mels, make_state_dict
     from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
 
-    dry = args.cpu_dry_run
-    if dry:
-        dev = torch.device('cpu')
-        if world > 1:
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('gloo')
-    else:
-        if not torch.cuda.is_available():
-            print('bench.py: no HIP device visible (the hot path has no CPU fallback)', file=sys.stderr)
-            return 3
-        torch.cuda.set_device(local_rank)
-        dev = torch.device('cuda', local_rank)
-        if world > 1:
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('nccl', device_id=dev)
-
-    cfg = CONFIGS[args.config]
-    mode, B = cfg['mode'], (args.batch or cfg['batch'])
+    cfg = CONFIGS[cfg_id]
+    mode, B = cfg['mode'], (batch or cfg['batch'])
+    use_pg = dist.is_initialized()
     # synthetic weights of the reference architecture + synthetic mel (no checkpoint ships: .MISSING_LARGE_BLOBS)
     sd = make_state_dict(0, mode=mode, variant='peaky' if mode == 'RAW' else 'default', bits=cfg['bits'])
     dims = dict(DEFAULT_DIMS)
@@ -175,17 +180,20 @@ def main() -> int:
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     if not dry:
         model.to(dev)
-    model.kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[args.kernel]
-    T = args.frames
-    scatter = args.config == 3
+    kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[kernel_name]
+    T = frames
+    scatter = cfg_id == 3
     if scatter and rank == 0:
         all_mels = torch.from_numpy(make_mels(1000, world * B, T)).to(dev)   # rank 0 owns the whole job, resident in HBM
         mels = torch.empty((B, 80, T), dtype=torch.float32, device=dev)
     elif scatter:
         all_mels, mels = None, torch.empty((B, 80, T), dtype=torch.float32, device=dev)
     else:
+        all_mels = None
         mels = torch.from_numpy(make_mels(1000 + rank, B, T)).to(dev)       # resident in HBM before timing
     nat = None if dry else model.native()
+    if phase_profile and nat is not None:
+        nat.phase_profile(True)
     rows, L = (B, T * HOP) if dry else nat.plan(B, T, False, 11000, 550)
     samples = torch.empty((rows, L), dtype=torch.float32, device=dev)
     labels = torch.empty((rows, L), dtype=torch.int32, device=dev)
@@ -194,42 +202,38 @@ def main() -> int:
     gathered = [torch.empty((rows, wave_len), dtype=torch.float64, device=dev) for _ in range(world)] if (scatter and rank == 0) else None
     stream = 0 if dry else torch.cuda.current_stream(dev).cuda_stream
 
+    def seed_of(i: int) -> int:
+        return 0xC0FFEE + 7919 * i + rank
+
     def one_step(i: int):
-        if scatter and world > 1:
+        if scatter:   # same calls at every N (a one-rank communicator at N=1)
             dist.scatter(mels, list(all_mels.view(world, B, 80, T).unbind(0)) if rank == 0 else None, src=0)
-        elif scatter:
-            mels.copy_(all_mels)
         if dry:   # stand-in for the device calls: every utterance's "waveform" is a function of its own mel only
             wave.copy_(mels.to(torch.float64).sum(dim=(1, 2))[:, None].expand(rows, wave_len))
-            if scatter and world > 1:
-                dist.gather(wave, gathered, dst=0)
-            return
-        nat.generate(mels.data_ptr(), B, T, False, 11000, 550, labels_ptr=labels.data_ptr(),
-                     samples_ptr=samples.data_ptr(), stream=stream, noise_mode=_cabi.NOISE_PHILOX,
-                     seed=0xC0FFEE + 7919 * i + rank, kernel=model.kernel)
-        # float64 tail of generate() (mu-law decode, trim, fade-out) on the device, for every utterance of the batch
-        # (wrnn_epilogue finishes one unbatched utterance per call, like :253)
-        for r in range(rows):
-            nat.epilogue(samples.data_ptr() + 4 * r * L, labels.data_ptr() + 4 * r * L, 1, L, False, 11000, 550, mode == 'RAW',
-                         wave_len, wave.data_ptr() + 8 * r * wave_len, stream)
-        if scatter and world > 1:
+        else:
+            nat.generate(mels.data_ptr(), B, T, False, 11000, 550, labels_ptr=labels.data_ptr(),
+                         samples_ptr=samples.data_ptr(), stream=stream, noise_mode=_cabi.NOISE_PHILOX,
+                         seed=seed_of(i), kernel=kernel)
+            # float64 tail of generate() (mu-law decode, trim, fade-out) on the device for every utterance of the batch, one launch
+            nat.epilogue_rows(samples.data_ptr(), labels.data_ptr(), rows, L, mode == 'RAW', wave_len, 0, wave.data_ptr(), wave_len, stream)
+        if scatter:
             dist.gather(wave, gathered, dst=0)
 
     def barrier():
         if not dry:
             torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_pg:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         one_step(-1 - i)
     barrier()
     loop_ms, pro_ms = [], []
     tm = None
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         one_step(i)
         tm = dict(kernel=0, loop_ms=1.0, prologue_ms=0.0, launches=1) if dry else nat.last_timing()   # waits for this step's kernels (HIP events on the launch stream)
         loop_ms.append(tm['loop_ms'])
@@ -237,59 +241,162 @@ def main() -> int:
     barrier()
     dt = time.perf_counter() - t0
     kernel_ran = tm['kernel'] if tm else 0
-    if world > 1:
+    if use_pg and world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    phases = None
+    if phase_profile and nat is not None:
+        phases = nat.phase_cycles()
+        nat.phase_profile(False)
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        total_samples = world * args.steps * rows * L
-        value = total_samples / dt / 1000.0
-        audio_s = (T - 1) * HOP / SAMPLE_RATE
-        k_ms = float(np.mean(loop_ms)) if loop_ms else float('nan')
-        launches = max(1, int(tm.get('launches', 1))) if tm else 1   # segments an utterance is generated in
-        bytes_per_sample = W_BYTES[mode] / rows + COND_BYTES
-        bw_bound = HBM_PEAK / bytes_per_sample
-        fl_bound = F32_PEAK / FLOP_PER_SAMPLE[mode]
-        rate = rows * L / (k_ms * 1e-3)                              # row-steps per second of the loop kernel alone
-        if fl_bound < bw_bound:
-            roof = {'bound': 'mfma', 'achieved': round(rate * FLOP_PER_SAMPLE[mode] / 1e12, 3), 'peak': F32_PEAK / 1e12, 'unit': 'TFLOP/s',
-                    'frac': round(rate / fl_bound, 4)}
-            roof_note = (f'achieved = {FLOP_PER_SAMPLE[mode]} FLOP/sample x {rows} rows x steps per launch / loop-kernel launch duration; '
-                         f'bound = fp32 matrix/vector peak (B={rows}: {fl_bound / 1e6:.1f} Msamples/s; the HBM bound would be {bw_bound / 1e6:.1f})')
-        else:
-            roof = {'bound': 'hbm', 'achieved': round(rate * bytes_per_sample / 1e9, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': round(rate / bw_bound, 4)}
-            roof_note = (f'achieved = algorithmic bytes ({bytes_per_sample:.0f} B/sample at B={rows}: weights once per step for the batch + 836 B) '
-                         f'x steps per launch / average loop-kernel launch duration (HIP events around the {launches} launch(es) of one call); '
-                         'the weights are register/LDS resident, so the kernel is latency/issue-bound, not HBM-bound: traffic = measured '
-                         'HBM bytes per launch where a PMC pass exists (profiles/)')
-        roof['traffic'] = TRAFFIC_BYTES_PER_LAUNCH.get((args.config, kernel_ran)) if T == T_FRAMES else None
-        roof['note'] = roof_note
-        out = {
-            'metric': f'audio ksamples/sec (22.05 kHz, {"10-bit RAW" if mode == "RAW" else "9-bit MOL"} WaveRNN, batch={B} per GPU)',
-            'value': round(value, 3), 'unit': 'ksamples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE {cfg["name"]}: {B} utterance(s) per GPU per step, mel 80x{T} '
-                                   f'({L} loop steps = {audio_s:.3f} s audio each), {"RAW 10-bit" if mode == "RAW" else "MOL 9-bit"}, hop 275, '
-                                   'prologue + loop + float64 epilogue on the device, Philox sampling noise, seeded synthetic weights'
-                                   + (', mels scattered from / waveforms gathered on rank 0 over RCCL inside the timed region' if scatter else ''),
-                       'kernel': _cabi.KERNEL_NAMES.get(kernel_ran, str(kernel_ran)),
-                       'real_time_factor': round((dt / args.steps) / (audio_s * rows), 5),
-                       'times_real_time': round(audio_s * rows / (dt / args.steps), 2),
-                       'prologue_ms': round(float(np.mean(pro_ms)), 3), 'loop_kernel_ms': round(k_ms, 3),
-                       'loop_launches_per_call': launches, 'loop_launch_avg_ms': round(k_ms / launches, 3),
-                       'us_per_step': round(k_ms * 1e3 / L, 4),
-                       'parallelism': f'utterance-parallel x{world} (no data-path collective' + (' but the scatter/gather of clips)' if scatter else ')')},
-            'roofline': roof,
-        }
-        if dry:
-            out['data'] = 'dry-run (CPU stand-in for the device calls: not a measurement)'
-            if scatter and world > 1:   # every rank's waveforms came back, and they are the ones of the clips it was sent
-                want = all_mels.view(world, B, 80, T).to(torch.float64).sum(dim=(2, 3))
-                ok = all(torch.equal(gathered[r][:, 0], want[r]) for r in range(world))
-                out['dry_run_check'] = 'ok' if ok else 'MISMATCH'
+    if dump:   # what the last timed step produced, for tests/test_gpu_config3.py
+        np.savez(dump, wave=torch.stack(gathered).cpu().numpy() if gathered is not None else wave.cpu().numpy()[None],
+                 labels=labels.cpu().numpy(), samples=samples.cpu().numpy(),   # rank 0's own rows
+                 seed=np.asarray([seed_of(steps - 1)], np.uint64), frames=T, batch=B, world=world, mel_seed=1000)
+    total_samples = world * steps * rows * L
+    value = total_samples / dt / 1000.0
+    audio_s = (T - 1) * HOP / SAMPLE_RATE
+    k_ms = float(np.mean(loop_ms)) if loop_ms else float('nan')
+    launches = max(1, int(tm.get('launches', 1))) if tm else 1   # segments an utterance is generated in
+    bytes_per_sample = W_BYTES[mode] / rows + COND_BYTES
+    bw_bound = HBM_PEAK / bytes_per_sample
+    fl_bound = F32_PEAK / FLOP_PER_SAMPLE[mode]
+    rate = rows * L / (k_ms * 1e-3)                              # row-steps per second of the loop kernel alone
+    us_per_step = k_ms * 1e3 / L
+    if fl_bound < bw_bound:
+        roof = {'bound': 'mfma', 'achieved': round(rate * FLOP_PER_SAMPLE[mode] / 1e12, 3), 'peak': F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': round(rate / fl_bound, 4)}
+        roof_note = (f'achieved = {FLOP_PER_SAMPLE[mode]} FLOP/sample x {rows} rows x steps per launch / loop-kernel launch duration; '
+                     f'bound = fp32 matrix/vector peak (B={rows}: {fl_bound / 1e6:.1f} Msamples/s; the HBM bound would be {bw_bound / 1e6:.1f})')
+    else:
+        roof = {'bound': 'hbm', 'achieved': round(rate * bytes_per_sample / 1e9, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                'frac': round(rate / bw_bound, 4)}
+        if copy_peak:
+            roof['peak_measured'] = round(copy_peak / 1e9, 1)
+            roof['frac_of_measured'] = round(rate * bytes_per_sample / copy_peak, 4)
+        roof_note = (f'achieved = algorithmic bytes ({bytes_per_sample:.0f} B/sample at B={rows}: weights once per step for the batch + 836 B) '
+                     f'x steps per launch / average loop-kernel launch duration (HIP events around the {launches} launch(es) of one call); '
+                     'peak = data-sheet HBM bandwidth, peak_measured = device-to-device copy (read + write) timed in this run.  NOTIONAL for '
+                     'this kernel: the weights are register/LDS resident and never leave the chip (traffic: measured HBM bytes per launch)')
+    roof['traffic'] = TRAFFIC_BYTES_PER_LAUNCH.get((cfg_id, kernel_ran)) if T == T_FRAMES else None
+    roof['traffic_source'] = TRAFFIC_SOURCE if roof['traffic'] is not None else None
+    if kernel_ran == _cabi.KERNEL_TEAM2 and rows <= 8:
+        lm = dict(LATENCY_MODEL)
+        lm['floor_us'] = round(lm['exchanges_per_step'] * lm['allgather_round_us'], 3)
+        roof['latency_model'] = lm
+        roof['frac_of_latency_floor'] = round(lm['floor_us'] / us_per_step, 4)
+        roof_note += ('; what binds is latency: latency_model.floor_us = 4 dependent all-gather rounds per step with no compute at all, '
+                      'frac_of_latency_floor = floor_us / measured us per step')
+    roof['note'] = roof_note
+    out = {
+        'metric': f'audio ksamples/sec (22.05 kHz, {"10-bit RAW" if mode == "RAW" else "9-bit MOL"} WaveRNN, batch={B} per GPU)',
+        'value': round(value, 3), 'unit': 'ksamples/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE {cfg["name"]}: {B} utterance(s) per GPU per step, mel 80x{T} '
+                               f'({L} loop steps = {audio_s:.3f} s audio each), {"RAW 10-bit" if mode == "RAW" else "MOL 9-bit"}, hop 275, '
+                               'prologue + loop + float64 epilogue on the device, Philox sampling noise, seeded synthetic weights'
+                               + (', mels scattered from / waveforms gathered on rank 0 over RCCL inside the timed region' if scatter else ''),
+                   'kernel': _cabi.KERNEL_NAMES.get(kernel_ran, str(kernel_ran)),
+                   'real_time_factor': round((dt / steps) / (audio_s * rows), 5),
+                   'times_real_time': round(audio_s * rows / (dt / steps), 2),
+                   'prologue_ms': round(float(np.mean(pro_ms)), 3), 'loop_kernel_ms': round(k_ms, 3),
+                   'loop_launches_per_call': launches, 'loop_launch_avg_ms': round(k_ms / launches, 3),
+                   'us_per_step': round(us_per_step, 4),
+                   'parallelism': f'utterance-parallel x{world} (no data-path collective' + (' but the scatter/gather of clips)' if scatter else ')')},
+        'roofline': roof,
+    }
+    if phases is not None:
+        out['phase_cycles_per_step'] = {f'wave{w}': [round(float(c)) for c in phases[w] if c > 0] for w in range(8) if phases[w].any()}
+    if dry:
+        out['data'] = 'dry-run (CPU stand-in for the device calls: not a measurement)'
+        if scatter and world > 1:   # every rank's waveforms came back, and they are the ones of the clips it was sent
+            want = all_mels.view(world, B, 80, T).to(torch.float64).sum(dim=(2, 3))
+            ok = all(torch.equal(gathered[r][:, 0], want[r]) for r in range(world))
+            out['dry_run_check'] = 'ok' if ok else 'MISMATCH'
+    del model
+    return out
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=0, help='ranks = GPUs of one node (default: WORLD_SIZE under torch.distributed.run, else 1)')
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument('--frames', type=int, default=T_FRAMES)
+    ap.add_argument('--batch', type=int, default=0, help='rows per GPU (default: the config\'s)')
+    ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'batch', 'simple'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the configs[2] / configs[4] legs of the default run')
+    ap.add_argument('--phase-profile', action='store_true', help='run the instrumented loop kernel (wrnn_phase_profile) and attach cycles per phase')
+    ap.add_argument('--dump', default=None, help='rank 0: save the waveforms of the last timed step (npz) -- used by tests/test_gpu_config3.py')
+    ap.add_argument('--cpu-dry-run', action='store_true',
+                    help='exercise the launcher / rendezvous / collectives / timing / JSON scaffolding on CPU (gloo) with a stand-in for the '
+                         'device calls: tests only, the line it prints is not a measurement')
+    args = ap.parse_args()
+
+    under_launcher = 'RANK' in os.environ
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus == 0:
+        args.gpus = world if under_launcher else 1
+    if args.gpus > 1 and not under_launcher:
+        return self_launch(args)
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+        return 2
+
+    import torch
+    import torch.distributed as dist
+
+    dry = args.cpu_dry_run
+    # configs[3] always runs its collectives, also on one rank: a standalone N=1 call provides its own rendezvous
+    need_pg = world > 1 or args.config == 3
+    if need_pg and not under_launcher:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            os.environ.setdefault('MASTER_PORT', str(s.getsockname()[1]))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if dry:
+        dev = torch.device('cpu')
+        if need_pg:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo')
+    else:
+        if not torch.cuda.is_available():
+            print('bench.py: no HIP device visible (the hot path has no CPU fallback)', file=sys.stderr)
+            return 3
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+        if need_pg:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('nccl', device_id=dev)
+
+    copy_peak = None if dry or rank != 0 else measure_copy_peak(dev)
+    out = run_config(args.config, world=world, rank=rank, dev=dev, dry=dry, steps=args.steps, warmup=args.warmup, frames=args.frames,
+                     batch=args.batch, kernel_name=args.kernel, copy_peak=copy_peak, dump=args.dump, phase_profile=args.phase_profile)
+    default_run = (args.config == 1 and world == 1 and not dry and not args.no_extra_configs and args.frames == T_FRAMES
+                   and args.batch == 0 and args.kernel == 'auto')
+    if rank == 0 and out is not None:
+        if default_run:
+            # configs[2] and [4] in the driver's own run: a few steps each, attached to the headline line
+            extra = {}
+            for cid in (2, 4):
+                try:
+                    e = run_config(cid, world=1, rank=0, dev=dev, dry=False, steps=2, warmup=1, frames=T_FRAMES, batch=0, kernel_name='auto',
+                                   copy_peak=copy_peak)
+                    extra[str(cid)] = {k: e[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'roofline')}
+                    extra[str(cid)]['config'] = e['config']
+                except Exception as ex:  # an extra leg must never sink the headline
+                    extra[str(cid)] = {'error': repr(ex)}
+            out['extra_configs'] = extra
         if world == 1 and not args.no_cpu_baseline and not dry:
             try:
                 out['cpu_baseline'] = cpu_baseline()
@@ -300,7 +407,7 @@ def main() -> int:
             if ref:
                 out['cpu_reference'] = ref
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -20,9 +20,17 @@
  * (wrnn_last_timing and wrnn_dm_sync_status wait; nothing else does).
  *
  * The TEAM2 / BATCH kernels keep n_teams * 32 workgroups spinning on each other inside one launch, so all of them
- * must be resident at once (one per CU): wrnn_create establishes that with the runtime's occupancy query and the CU
- * count; on a device where it does not hold (partitioned / shared GPU) AUTO uses the SIMPLE kernel and an explicit
- * request for a team kernel fails with WRNN_ERR_INVALID.  Do not run two team-kernel calls concurrently on one device.
+ * must be resident at once (one per CU).  Three layers make that a checked fact instead of a rule for the caller:
+ *   1. wrnn_create asks the runtime's occupancy query about the instantiations this handle can launch (mode, profile
+ *      build) and reads the CU count; where a team kernel cannot be resident (LDS / registers, fewer than 32 CUs) AUTO
+ *      uses the SIMPLE kernel and an explicit request for a team kernel fails with WRNN_ERR_INVALID.
+ *   2. Inside one process every team-kernel launch on a device -- any handle, any stream, wrnn_generate and
+ *      wrnn_dm_generate alike -- is ordered behind the previous one with a per-device event (stream wait, nothing blocks
+ *      on the host): two handles (RAW + MOL, two threads) share a GPU safely.
+ *   3. Across processes nothing can be ordered; a team kernel whose workgroups do not all become resident within a short
+ *      bounded wait at its start (another process holds CUs) gives up at once and the call reports WRNN_ERR_BUSY through
+ *      wrnn_last_timing / wrnn_dm_sync_status -- retry, or use WRNN_KERNEL_SIMPLE.  The occupancy query cannot see other
+ *      processes; this run-time check is what covers a shared GPU.
  */
 #ifndef WAVERNN_AMD_H
 #define WAVERNN_AMD_H
@@ -33,7 +41,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 3
+#define WRNN_ABI_VERSION 4
 
 /* mode: fatchord_version.py:98-103 */
 #define WRNN_MODE_RAW 0 /* softmax over 2**bits classes */
@@ -63,6 +71,7 @@ extern "C" {
 #define WRNN_ERR_STATE -3       /* e.g. generate before load_weights */
 #define WRNN_ERR_MISSING_KEY -4 /* state_dict key absent (strict load) */
 #define WRNN_ERR_TIMEOUT -5     /* a bounded device spin gave up */
+#define WRNN_ERR_BUSY -6        /* a team kernel could not get all its workgroups resident (GPU shared with another process) */
 
 typedef struct wrnn_handle wrnn_handle;
 
@@ -97,8 +106,15 @@ typedef struct wrnn_tensor_desc {
 } wrnn_tensor_desc;
 
 typedef struct wrnn_sample_opts {
+    /* = sizeof(wrnn_sample_opts) of the CALLER.  The library refuses a size it does not know (WRNN_ERR_INVALID): a caller
+     * built against another ABI revision fails loudly instead of having its fields read at shifted offsets. */
+    uint32_t struct_size;
     int32_t noise_mode; /* WRNN_NOISE_* */
     int32_t kernel;     /* WRNN_KERNEL_* */
+    /* != 0: mels_dev is (B, feat, T + 2*pad), already padded by `pad` frames on both sides with real context like the
+     * training collate does and WaveRNN.forward receives it (:143); 0: (B, feat, T), zero padding applied on the fly
+     * like generate() (:183-185).  T is the unpadded frame count either way. */
+    int32_t mels_padded;
     uint64_t seed;      /* WRNN_NOISE_PHILOX */
     /* WRNN_NOISE_INJECTED, device pointers, step-major like the reference's
      * RNG consumption (one sampler call per step, batch inside):
@@ -115,11 +131,19 @@ typedef struct wrnn_sample_opts {
      * the teacher-forced pass of WaveRNN.forward (fatchord_version.py:131-167): input sequence x[0..L) = x_init,
      * x_forced[0..L-1), logits in logits_out_dev. */
     const float *x_init_dev;
-    /* != 0: mels_dev is (B, feat, T + 2*pad), already padded by `pad` frames on both sides with real context like the
-     * training collate does and WaveRNN.forward receives it (:143); 0: (B, feat, T), zero padding applied on the fly
-     * like generate() (:183-185).  T is the unpadded frame count either way. */
-    int32_t mels_padded;
-    int32_t reserved_;
+    /* Ragged batch (unbatched mode only), device pointer to B int32 or NULL: utterance b has frames_dev[b] valid mel
+     * frames (1 <= frames_dev[b] <= T; mels_dev stays (B, feat, T), zero beyond an utterance's own frames -- the padding
+     * generate() itself applies, :183).  Row b then runs frames_dev[b] * hop steps instead of T * hop: its first
+     * frames_dev[b] * hop outputs are exactly what a call on that clip alone produces (rows are independent, :194-196;
+     * the noise is keyed by (row, step)), the rest of the row is left unwritten.  The library orders the rows by length
+     * on the device (longest first), fills team batches with rows of similar length and deals the batches to the teams
+     * in snake order, so that no team idles behind a long clip. */
+    const int32_t *frames_dev;
+    /* tuning, 0 = the library's choice.  batch_rows: rows per team batch of WRNN_KERNEL_BATCH, 1..8 (default
+     * ceil(rows / teams), at most 8).  team2_segment: steps per launch of WRNN_KERNEL_TEAM2 (a row is generated in
+     * segments so that the conditioning stream of one segment stays cache resident; rounded down to a multiple of 32). */
+    int32_t batch_rows;
+    int32_t team2_segment;
 } wrnn_sample_opts;
 
 typedef struct wrnn_timing {
@@ -175,6 +199,16 @@ int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int32_t *label
                   int32_t batched, int32_t target, int32_t overlap, int32_t mu_law, int64_t wave_len,
                   double *wave_out_dev, void *stream);
 
+/* The same tail for a batch of INDEPENDENT utterances (throughput mode, generate_many): every row r is finished like an
+ * unbatched call finishes row 0 -- decode_mu_law (when mu_law != 0 on a RAW model), trim, 20-hop fade-out -- in ONE launch:
+ *   wave_out_dev[r * out_stride + n], n < wave_len_r;  wave_len_r = wave_len, or (frames_dev[r] - 1) * hop when frames_dev
+ *   (device, rows int32, the array given to wrnn_generate) is not NULL; out_stride >= wave_len doubles per row, entries
+ *   [wave_len_r, out_stride) of a row are set to 0.  A row shorter than the 20-hop fade-out (the reference raises
+ *   ValueError for T < 21, :256-258) is all zeros: the host side of the binding rejects such clips before the call. */
+int wrnn_epilogue_rows(wrnn_handle *h, const float *samples_dev, const int32_t *labels_dev, int32_t rows, int64_t steps,
+                       int32_t mu_law, int64_t wave_len, const int32_t *frames_dev, double *wave_out_dev, int64_t out_stride,
+                       void *stream);
+
 /* Host-only helper (no device): the float64 tables wrnn_epilogue gathers from, built in NumPy's evaluation order --
  * dec[n_classes] (decode_mu_law of 2k/(n_classes-1)-1, dsp.py:98-103), fade_in/fade_out[overlap] (:374-385, may be
  * NULL when overlap == 0), tail[20*hop] (np.linspace(1, 0, 20*hop_length), :256).  Caller-allocated. */
@@ -189,9 +223,44 @@ int wrnn_epilogue_tables(int32_t n_classes, int32_t overlap, int32_t hop, double
  * loss_out_dev: one float32 on the device.  Asynchronous on `stream`. */
 int wrnn_loss(wrnn_handle *h, const float *y_hat_dev, const void *y_dev, int64_t n_rows, float *loss_out_dev, void *stream);
 
+/* ---- training step of the loop layers -------------------------------------------------------------------
+ * WaveRNN.forward (fatchord_version.py:131-167) from the upsampled conditioning on, the training script's loss
+ * (wavernn_train.py:82,112-121) and the backward pass of `loss.backward()` through I, rnn1, rnn2, fc1, fc2, fc3.
+ * Every pointer is a DEVICE pointer to a contiguous float32 tensor in the reference's own layout (nn.Linear / nn.GRU:
+ * weight (out, in), gate rows r | z | n) -- the parameters are used where torch keeps them, nothing is repacked, so an
+ * optimizer step between two calls costs nothing here. */
+typedef struct wrnn_loop_params {
+    float *I_w, *I_b;                                   /* (rnn, 1 + feat + aux), (rnn)                 :115 */
+    float *rnn1_w_ih, *rnn1_w_hh, *rnn1_b_ih, *rnn1_b_hh; /* (3 rnn, rnn) x2, (3 rnn) x2                  :117 */
+    float *rnn2_w_ih, *rnn2_w_hh, *rnn2_b_ih, *rnn2_b_hh; /* (3 rnn, rnn + aux), (3 rnn, rnn), (3 rnn) x2 :118 */
+    float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b; /* (fc, rnn + aux), (fc, fc + aux), (n_classes, fc) :121-123 */
+} wrnn_loop_params;
+
+/*   w            parameters (read)
+ *   g            gradients of the MEAN loss, same shapes (overwritten, not accumulated), or NULL: forward + loss only
+ *   x_dev        (B, L) input samples                     mels_up_dev (B, L, feat), aux_dev (B, L, res_out): what
+ *                self.upsample(mels) returns (:143), computed by the caller (the upsample network trains through the
+ *                framework's autograd: BatchNorm in training mode needs batch statistics)
+ *   y_dev        (B, L) targets: int32 class labels (RAW) / float32 in [-1, 1] (MOL); may be NULL when g and loss_out_dev are
+ *   loss_out_dev one float32 (F.cross_entropy / discretized_mix_logistic_loss, as wrnn_loss) or NULL
+ *   logits_out_dev (B, L, n_classes) fc3 outputs = forward()'s return value, or NULL
+ *   d_mels_up_dev, d_aux_dev  gradients w.r.t. the conditioning (same shapes; written when g != NULL), or NULL
+ * The handle supplies dims / mode and owns the workspace (grown on demand, ~86 KB per (batch, step) pair at the default
+ * dims) and the captured step graphs; it needs no loaded weights.  Asynchronous on `stream`. */
+int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_params *g, const float *x_dev,
+                    const float *mels_up_dev, const float *aux_dev, const void *y_dev, int32_t B, int64_t L,
+                    float *loss_out_dev, float *logits_out_dev, float *d_mels_up_dev, float *d_aux_dev, void *stream);
+
 /* Blocks until the last wrnn_generate on this handle finished, then reports
  * HIP-event timings and any device-side error (WRNN_ERR_TIMEOUT). */
 int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out);
+
+/* Developer instrumentation (replaces the WRNN_TEAM_PROF environment variable of ABI 3): enable != 0 makes the following
+ * TEAM2 / BATCH calls of this handle run the instrumented instantiation of the loop kernel (s_memtime stamps between the
+ * phases of a step; ~1 % slower).  wrnn_phase_cycles waits for the last call and returns, for workgroup 0 of team 0,
+ * cycles per step of every phase marker: out[wave * 32 + marker], 8 waves x 32 markers (unused entries 0). */
+int wrnn_phase_profile(wrnn_handle *h, int32_t enable);
+int wrnn_phase_cycles(wrnn_handle *h, double *out /* [8 * 32] */);
 
 /* n_classes (fatchord_version.py:98-101) and loop-parameter bytes (roofline) */
 int32_t wrnn_n_classes(const wrnn_handle *h);

@@ -267,16 +267,17 @@ static void gru_cell(const float *wih, const float *whh, const float *bih, const
  *   margin_out (L, B) or NULL: relative gap between the winning and runner-up
  *          race scores (how close the step was to a tie), runner_out (L,B)
  */
-int wo_loop(const wo_dims *d, const wo_weights *w, const float *cond_m, const float *cond_a, int B,
-            long L, int noise_mode, const float *noise1, const float *noise2, const float *x_forced,
-            int32_t *labels, float *samples, float *logits_out, float *margin_out,
-            int32_t *runner_out) {
+static int loop_row(const wo_dims *d, const wo_weights *w, const float *cond_m, const float *cond_a, int B, int b,
+                    long L, int noise_mode, const float *noise1, const float *noise2, const float *x_forced,
+                    int32_t *labels, float *samples, float *logits_out, float *margin_out,
+                    int32_t *runner_out) {
     const int H = d->rnn_dims, FC = d->fc_dims, F = d->feat_dims, A = d->aux_dims;
     const int R = d->res_out_dims, NC = d->n_classes;
     const int in_I = 1 + F + A;
-    float *h1 = (float *)calloc((size_t)B * H, sizeof(float));   /* :194 */
-    float *h2 = (float *)calloc((size_t)B * H, sizeof(float));   /* :195 */
-    float *xprev = (float *)calloc((size_t)B, sizeof(float));    /* :196 */
+    /* state of row b only: the rows of a batch never interact (:194-196 zero state per row, every op is row-wise) */
+    float *h1 = (float *)calloc((size_t)H, sizeof(float));   /* :194 */
+    float *h2 = (float *)calloc((size_t)H, sizeof(float));   /* :195 */
+    float xprev = 0.0f;                                       /* :196 */
     float *cat = (float *)malloc((size_t)((H > FC ? H : FC) + A + in_I) * sizeof(float));   /* holds [x | a] of every layer */
     float *x = (float *)malloc((size_t)H * sizeof(float));
     float *gi = (float *)malloc((size_t)3 * H * sizeof(float));
@@ -285,15 +286,15 @@ int wo_loop(const wo_dims *d, const wo_weights *w, const float *cond_m, const fl
     float *f2 = (float *)malloc((size_t)FC * sizeof(float));
     float *lg = (float *)malloc((size_t)NC * sizeof(float));
     float *p = (float *)malloc((size_t)NC * sizeof(float));
-    if (!h1 || !h2 || !xprev || !cat || !x || !gi || !gh || !f1 || !f2 || !lg || !p) return -1;
+    if (!h1 || !h2 || !cat || !x || !gi || !gh || !f1 || !f2 || !lg || !p) return -1;
 
     for (long t = 0; t < L; ++t) {
-        for (int b = 0; b < B; ++b) {
+        {
             const float *m_t = cond_m + ((size_t)b * L + t) * F;
             const float *a_t = cond_a + ((size_t)b * L + t) * R;
-            float *hb1 = h1 + (size_t)b * H, *hb2 = h2 + (size_t)b * H;
+            float *hb1 = h1, *hb2 = h2;
             /* x = I(cat[x, m_t, a1_t]) :208-209 */
-            cat[0] = xprev[b];
+            cat[0] = xprev;
             memcpy(cat + 1, m_t, (size_t)F * sizeof(float));
             memcpy(cat + 1 + F, a_t, (size_t)A * sizeof(float));
             matvec(w->I_w, w->I_b, cat, x, H, in_I);
@@ -373,12 +374,42 @@ int wo_loop(const wo_dims *d, const wo_weights *w, const float *cond_m, const fl
             samples[(size_t)t * B + b] = sample;
             if (margin_out) margin_out[(size_t)t * B + b] = margin;
             if (runner_out) runner_out[(size_t)t * B + b] = runner;
-            xprev[b] = x_forced ? x_forced[(size_t)t * B + b] : sample;  /* :228,:237 */
+            xprev = x_forced ? x_forced[(size_t)t * B + b] : sample;  /* :228,:237 */
         }
     }
-    free(h1); free(h2); free(xprev); free(cat); free(x); free(gi); free(gh);
+    free(h1); free(h2); free(cat); free(x); free(gi); free(gh);
     free(f1); free(f2); free(lg); free(p);
     return 0;
+}
+
+/* All B rows.  The rows are independent, so the order in which (row, step) pairs are evaluated is free: with few rows each
+ * row is walked with the matvecs split over the OpenMP team (as a B = 1 call always was); with >= 4 rows the ROWS are split
+ * over the team and every row runs its matvecs on one thread (the nested `parallel for` inside matvec is then serial: nested
+ * parallelism is off by default) -- no fork/join per layer, and each core streams the weights from its own cache.  The
+ * arithmetic of a row is the same instruction sequence either way. */
+int wo_loop(const wo_dims *d, const wo_weights *w, const float *cond_m, const float *cond_a, int B,
+            long L, int noise_mode, const float *noise1, const float *noise2, const float *x_forced,
+            int32_t *labels, float *samples, float *logits_out, float *margin_out,
+            int32_t *runner_out) {
+    int rc = 0;
+#ifdef _OPENMP
+    if (B >= 4 && omp_get_max_threads() > 1) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b) {
+            const int r = loop_row(d, w, cond_m, cond_a, B, b, L, noise_mode, noise1, noise2, x_forced, labels, samples, logits_out,
+                                   margin_out, runner_out);
+            if (r) {
+#pragma omp atomic write
+                rc = r;
+            }
+        }
+        return rc;
+    }
+#endif
+    for (int b = 0; b < B && !rc; ++b)
+        rc = loop_row(d, w, cond_m, cond_a, B, b, L, noise_mode, noise1, noise2, x_forced, labels, samples, logits_out, margin_out,
+                      runner_out);
+    return rc;
 }
 
 int wo_num_threads(void) {

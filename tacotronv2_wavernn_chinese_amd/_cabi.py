@@ -22,12 +22,14 @@ KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM2, KERNEL_BATCH = 0, 1, 3, 4
 KERNEL_NAMES = {KERNEL_AUTO: 'auto', KERNEL_SIMPLE: 'simple', KERNEL_TEAM2: 'team2', KERNEL_BATCH: 'batch'}
 DTYPE_F32, DTYPE_I64 = 0, 1
 ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN_ERR_STATE',
-             -4: 'WRNN_ERR_MISSING_KEY', -5: 'WRNN_ERR_TIMEOUT'}
+             -4: 'WRNN_ERR_MISSING_KEY', -5: 'WRNN_ERR_TIMEOUT', -6: 'WRNN_ERR_BUSY'}
+ABI_VERSION = 4   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding was written against
 
 # every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
-                    'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_tables', 'wrnn_loss',
+                    'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_rows', 'wrnn_epilogue_tables', 'wrnn_loss',
+                    'wrnn_phase_profile', 'wrnn_phase_cycles',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
                     'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
 
@@ -65,9 +67,10 @@ class TensorDesc(C.Structure):
 
 
 class SampleOpts(C.Structure):
-    _fields_ = [('noise_mode', C.c_int32), ('kernel', C.c_int32), ('seed', C.c_uint64),
-                ('noise1_dev', C.c_void_p), ('noise2_dev', C.c_void_p), ('x_forced_dev', C.c_void_p),
-                ('logits_out_dev', C.c_void_p), ('x_init_dev', C.c_void_p), ('mels_padded', C.c_int32), ('reserved_', C.c_int32)]
+    _fields_ = [('struct_size', C.c_uint32), ('noise_mode', C.c_int32), ('kernel', C.c_int32), ('mels_padded', C.c_int32),
+                ('seed', C.c_uint64), ('noise1_dev', C.c_void_p), ('noise2_dev', C.c_void_p), ('x_forced_dev', C.c_void_p),
+                ('logits_out_dev', C.c_void_p), ('x_init_dev', C.c_void_p), ('frames_dev', C.c_void_p),
+                ('batch_rows', C.c_int32), ('team2_segment', C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -109,6 +112,12 @@ def load_library() -> C.CDLL:
             f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950).  There is no fallback path.')
     lib = C.CDLL(LIB_PATH)
+    lib.wrnn_abi_version.argtypes = []
+    lib.wrnn_abi_version.restype = C.c_int32
+    got = int(lib.wrnn_abi_version())
+    if got != ABI_VERSION:   # the .so is a git-ignored build artefact: a stale one would read the structs at shifted offsets
+        raise RuntimeError(f'{LIB_PATH} implements ABI {got}, this binding needs ABI {ABI_VERSION}: rebuild it '
+                           '(`python -c "import __graft_entry__ as g; g.build()"`)')
     vp = C.c_void_p
     lib.wrnn_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.wrnn_create.restype = C.c_int
@@ -125,6 +134,12 @@ def load_library() -> C.CDLL:
     lib.wrnn_epilogue.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                   vp, vp]
     lib.wrnn_epilogue.restype = C.c_int
+    lib.wrnn_epilogue_rows.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, vp, vp, C.c_int64, vp]
+    lib.wrnn_epilogue_rows.restype = C.c_int
+    lib.wrnn_phase_profile.argtypes = [vp, C.c_int32]
+    lib.wrnn_phase_profile.restype = C.c_int
+    lib.wrnn_phase_cycles.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.wrnn_phase_cycles.restype = C.c_int
     lib.wrnn_epilogue_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.wrnn_epilogue_tables.restype = C.c_int
     lib.wrnn_loss.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
@@ -137,8 +152,6 @@ def load_library() -> C.CDLL:
     lib.wrnn_loop_weight_bytes.restype = C.c_int64
     lib.wrnn_last_error.argtypes = [vp]
     lib.wrnn_last_error.restype = C.c_char_p
-    lib.wrnn_abi_version.argtypes = []
-    lib.wrnn_abi_version.restype = C.c_int32
     lib.wrnn_destroy.argtypes = [vp]
     lib.wrnn_destroy.restype = None
     lib.wrnn_dm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
@@ -243,8 +256,12 @@ class NativeVocoder:
     def generate(self, mels_ptr: int, B: int, T: int, batched: bool, target: int, overlap: int, *,
                  labels_ptr: int, samples_ptr: int, stream: int, noise_mode: int = NOISE_PHILOX, seed: int = 0,
                  noise1_ptr: int = 0, noise2_ptr: int = 0, x_forced_ptr: int = 0, logits_ptr: int = 0,
-                 kernel: int = KERNEL_AUTO, x_init_ptr: int = 0, mels_padded: bool = False):
+                 kernel: int = KERNEL_AUTO, x_init_ptr: int = 0, mels_padded: bool = False, frames_ptr: int = 0,
+                 batch_rows: int = 0, team2_segment: int = 0):
         o = SampleOpts()
+        o.struct_size = C.sizeof(SampleOpts)
+        o.frames_dev = frames_ptr or None
+        o.batch_rows, o.team2_segment = int(batch_rows), int(team2_segment)
         o.noise_mode, o.kernel, o.seed = noise_mode, kernel, seed & 0xFFFFFFFFFFFFFFFF
         o.noise1_dev, o.noise2_dev = noise1_ptr or None, noise2_ptr or None
         o.x_forced_dev, o.logits_out_dev = x_forced_ptr or None, logits_ptr or None
@@ -258,6 +275,22 @@ class NativeVocoder:
         self._check(self.lib.wrnn_epilogue(self._h, samples_ptr, labels_ptr or None, rows, steps, int(bool(batched)),
                                            int(target), int(overlap), int(bool(mu_law)), int(wave_len), out_ptr,
                                            stream or None))
+
+    def epilogue_rows(self, samples_ptr: int, labels_ptr: int, rows: int, steps: int, mu_law: bool, wave_len: int,
+                      frames_ptr: int, out_ptr: int, out_stride: int, stream: int):
+        """Every row finished as an independent unbatched utterance, one launch (``wrnn_epilogue_rows``)."""
+        self._check(self.lib.wrnn_epilogue_rows(self._h, samples_ptr, labels_ptr or None, rows, steps, int(bool(mu_law)),
+                                                int(wave_len), frames_ptr or None, out_ptr, int(out_stride), stream or None))
+
+    def phase_profile(self, enable: bool = True):
+        """Developer instrumentation: the following TEAM2 / BATCH calls run the instrumented loop kernel."""
+        self._check(self.lib.wrnn_phase_profile(self._h, int(bool(enable))))
+
+    def phase_cycles(self) -> np.ndarray:
+        """(8 waves, 32 markers) cycles per step of workgroup 0 of team 0 for the last instrumented call."""
+        out = np.zeros(8 * 32, np.float64)
+        self._check(self.lib.wrnn_phase_cycles(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.reshape(8, 32)
 
     def loss(self, y_hat_ptr: int, y_ptr: int, n_rows: int, out_ptr: int, stream: int):
         self._check(self.lib.wrnn_loss(self._h, y_hat_ptr, y_ptr, int(n_rows), out_ptr, stream or None))

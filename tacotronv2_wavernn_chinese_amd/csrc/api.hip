@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 #include "wrnn_internal.h"
 
@@ -68,7 +69,33 @@ struct TensorView {
     const float *f() const { return (const float *)t->data; }
 };
 
+// Per-device ordering of team-kernel launches (wrnn_internal.h).  One slot per HIP device ordinal: the launch lock and an
+// event recorded behind the last team kernel; the next launch (any handle, any stream) waits on that event on the device.
+struct TeamGate {
+    std::mutex mu;
+    hipEvent_t tail = nullptr;
+    bool recorded = false;
+};
+TeamGate g_team_gate[64];
+
 }  // namespace
+
+hipError_t wrnn_team_gate_enter(int device, hipStream_t s) {
+    TeamGate &g = g_team_gate[(unsigned)device % 64u];
+    g.mu.lock();
+    hipError_t e = hipSuccess;
+    if (!g.tail) e = hipEventCreateWithFlags(&g.tail, hipEventDisableTiming);
+    if (e == hipSuccess && g.recorded) e = hipStreamWaitEvent(s, g.tail, 0);
+    if (e != hipSuccess) g.mu.unlock();
+    return e;
+}
+hipError_t wrnn_team_gate_leave(int device, hipStream_t s) {
+    TeamGate &g = g_team_gate[(unsigned)device % 64u];
+    hipError_t e = g.tail ? hipEventRecord(g.tail, s) : hipSuccess;
+    if (e == hipSuccess) g.recorded = true;
+    g.mu.unlock();
+    return e;
+}
 
 extern "C" {
 
@@ -124,14 +151,15 @@ int wrnn_create(const wrnn_config *cfg, wrnn_handle **out) {
         h->team_ok = true;
         if (!h->team_dims || d.NC > 1024) { h->team_ok = false; h->team_why = "the team kernels are built for rnn=fc=512, feat=80, compute=res_out=128, n_classes <= 1024"; }
         else if (h->n_teams < 1) { h->team_ok = false; h->team_why = "fewer than 32 CUs visible (one team = the 32 CUs of an XCD)"; }
+        // the instantiations THIS handle launches (its mode; the instrumented builds are checked by wrnn_phase_profile)
         int blocks = 0;
         size_t lds = 0;
         if (h->team_ok) {
-            hipError_t e = wrnn_team2_occupancy(&blocks, &lds);
+            hipError_t e = wrnn_team2_occupancy(cfg->mode, false, &blocks, &lds);
             if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_team2_kernel cannot be resident (LDS/registers)"; }
         }
         for (int nq = 1; nq <= 2 && h->team_ok; ++nq) {
-            hipError_t e = wrnn_batch_occupancy(nq, &blocks, &lds);
+            hipError_t e = wrnn_batch_occupancy(cfg->mode, nq, false, &blocks, &lds);
             if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_batch_kernel cannot be resident (LDS/registers)"; }
         }
         (void)hipGetLastError();
@@ -148,6 +176,9 @@ void wrnn_destroy(wrnn_handle *h) {
     if (h->wdev) (void)hipFree(h->wdev);
     if (h->aux_frames) (void)hipFree(h->aux_frames);
     if (h->rows_dev) (void)hipFree(h->rows_dev);
+    if (h->order_dev) (void)hipFree(h->order_dev);
+    if (h->sched_dev) (void)hipFree(h->sched_dev);
+    if (h->prof) (void)hipFree(h->prof);
     if (h->err_dev) (void)hipFree(h->err_dev);
     if (h->team_w) (void)hipFree(h->team_w);
     if (h->team_fc3) (void)hipFree(h->team_fc3);
@@ -161,6 +192,7 @@ void wrnn_destroy(wrnn_handle *h) {
     if (h->team_state) (void)hipFree(h->team_state);
     if (h->epi_tab) (void)hipFree(h->epi_tab);
     if (h->loss_partial) (void)hipFree(h->loss_partial);
+    if (h->train) wrnn_train_state_free(h->train);
     if (h->mail) (void)hipFree(h->mail);
     if (h->ctl) (void)hipFree(h->ctl);
     for (int i = 0; i < 3; ++i)
@@ -391,7 +423,6 @@ int wrnn_load_weights(wrnn_handle *h, const wrnn_tensor_desc *tensors, int32_t n
     if (!h->mail) {
         HIP_TRY(h, hipMalloc(&h->mail, (size_t)8 * WRNN_MAIL_GRANULES_MAX * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->ctl, 128));
-        if (getenv("WRNN_TEAM_PROF")) { HIP_TRY(h, hipMalloc(&h->prof, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long))); }
     }
     if (h->wdev) { (void)hipFree(h->wdev); h->wdev = nullptr; }
     HIP_TRY(h, hipMalloc(&h->wdev, o.total * sizeof(float)));
@@ -450,7 +481,13 @@ int wrnn_plan(wrnn_handle *h, int32_t B, int32_t T, int32_t batched, int32_t tar
 int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, int32_t batched, int32_t target, int32_t overlap,
                   const wrnn_sample_opts *opts, int32_t *labels_out_dev, float *samples_out_dev, void *stream) {
     if (!h || !mels_dev || !opts || !samples_out_dev) return fail(h, WRNN_ERR_INVALID, "wrnn_generate: bad arguments");
+    if (opts->struct_size != sizeof(wrnn_sample_opts))
+        return fail(h, WRNN_ERR_INVALID, "wrnn_sample_opts.struct_size is %u, this library (ABI %d) expects %zu: caller built against another revision of wavernn_amd.h",
+                    opts->struct_size, WRNN_ABI_VERSION, sizeof(wrnn_sample_opts));
     if (!h->loaded) return fail(h, WRNN_ERR_STATE, "weights not loaded");
+    if (opts->frames_dev && batched) return fail(h, WRNN_ERR_INVALID, "frames_dev (ragged batch) is for unbatched calls: folds of one utterance have one length");
+    if (opts->batch_rows < 0 || opts->batch_rows > WRNN_BATCH_MAX_ROWS) return fail(h, WRNN_ERR_INVALID, "batch_rows must be 0 (default) or 1..%d", WRNN_BATCH_MAX_ROWS);
+    if (opts->team2_segment < 0) return fail(h, WRNN_ERR_INVALID, "team2_segment must be >= 0");
     const WrnnDims &d = h->d;
     int32_t rows = 0;
     int64_t steps = 0;
@@ -467,10 +504,20 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     if ((size_t)rows > h->rows_cap) {
         if (h->rows_dev) (void)hipFree(h->rows_dev);
         h->rows_dev = nullptr; h->rows_cap = 0;
+        if (h->order_dev) (void)hipFree(h->order_dev);
+        if (h->sched_dev) (void)hipFree(h->sched_dev);
+        h->order_dev = h->sched_dev = nullptr;
         HIP_TRY(h, hipMalloc(&h->rows_dev, (size_t)rows * sizeof(WrnnRow)));
+        HIP_TRY(h, hipMalloc(&h->order_dev, (size_t)rows * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&h->sched_dev, ((size_t)rows + 64) * sizeof(int32_t)));
         h->rows_cap = rows;
     }
-    HIP_TRY(h, wrnn_launch_rows(h->rows_dev, rows, batched, (long)target + overlap, s));
+    const int sched_teams = h->n_teams < 1 ? 1 : h->n_teams;
+    const int n_slots = (rows + sched_teams - 1) / sched_teams * sched_teams;
+    HIP_TRY(h, wrnn_launch_rows(h->rows_dev, h->order_dev, h->sched_dev, rows, sched_teams, batched, (long)target + overlap, (long)steps,
+                                opts->frames_dev, T, d.HOP, s));
+    const int snake = opts->frames_dev ? 1 : 0;
+    unsigned long long *const prof = h->prof_on ? h->prof : nullptr;
     if (int rc = ensure_aux(h, B, T)) return rc;
     HIP_TRY(h, hipMemsetAsync(h->err_dev, 0, 64, s));
 
@@ -531,31 +578,36 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             HIP_TRY(h, wrnn_launch_pack_records32(tCM, tCA, tVM, tVA, tC2, tC3, tC4, tREC, B, T, P, s));
             int rpb = (rows + h->n_teams - 1) / h->n_teams;
             if (rpb > WRNN_BATCH_MAX_ROWS) rpb = WRNN_BATCH_MAX_ROWS;
-            if (const char *e = getenv("WRNN_BATCH_ROWS")) { rpb = atoi(e); if (rpb < 1) rpb = 1; if (rpb > WRNN_BATCH_MAX_ROWS) rpb = WRNN_BATCH_MAX_ROWS; }   // developer knob
+            if (opts->batch_rows > 0) rpb = opts->batch_rows;
             WrnnBatchArgs ba{};
             ba.w = w; ba.off = o; ba.d = d; ba.batch_w = h->batch_w; ba.batch_fc3 = h->batch_fc3; ba.batch_wn = h->batch_wn; ba.wI0 = h->wI0; ba.u1 = h->u1;
-            ba.tabREC32 = tREC; ba.rows = h->rows_dev; ba.n_rows = rows; ba.n_teams = h->n_teams; ba.nq = rpb <= 4 ? 1 : 2; ba.rpb = rpb;
+            ba.tabREC32 = tREC; ba.rows = h->rows_dev; ba.order = h->order_dev; ba.snake = snake; ba.n_rows = rows; ba.n_teams = h->n_teams; ba.nq = rpb <= 4 ? 1 : 2; ba.rpb = rpb;
             ba.T = T; ba.total_len = a.total_len; ba.steps = steps;
             ba.noise_mode = a.noise_mode; ba.seed = a.seed; ba.noise1 = a.noise1; ba.noise2 = a.noise2; ba.x_forced = a.x_forced; ba.x_init = a.x_init;
             ba.logits_out = a.logits_out; ba.labels_out = a.labels_out; ba.samples_out = a.samples_out;
-            ba.mail = h->mail; ba.ctl = h->ctl; ba.err = h->err_dev; ba.prof = h->prof;
-            if (const char *e = getenv("WRNN_BATCH_PP")) ba.variant = atoi(e) & 1;   // developer knob: ping-pong schedule of the 8-row kernel (loop_batch.hip), off until measured
-            HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
-            HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
-            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long), s));
+            ba.mail = h->mail; ba.ctl = h->ctl; ba.err = h->err_dev; ba.prof = prof;
+            if (prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long), s));
             HIP_TRY(h, hipEventRecord(h->ev[1], s));  // tables and records are prologue work
-            HIP_TRY(h, wrnn_launch_loop_batch(ba, s));
+            // team kernels of one device run one after the other, whatever handle / stream launches them (wavernn_amd.h); the
+            // mailbox reset belongs inside the gate: the handle's previous team kernel may still be reading it
+            HIP_TRY(h, wrnn_team_gate_enter(h->cfg.device, s));
+            hipError_t le = hipMemsetAsync(h->mail, 0, mail_bytes, s);
+            if (le == hipSuccess) le = hipMemsetAsync(h->ctl, 0, 128, s);
+            if (le == hipSuccess) le = wrnn_launch_loop_batch(ba, s);
+            const hipError_t ge = wrnn_team_gate_leave(h->cfg.device, s);
+            HIP_TRY(h, le);
+            HIP_TRY(h, ge);
             h->prof_div = (double)steps * ((((rows + rpb - 1) / rpb) + h->n_teams - 1) / h->n_teams);
         } else {
         HIP_TRY(h, wrnn_launch_pack_records(tCM, tCA, tVM, tVA, tREC, B, T, P, s));
         WrnnTeamArgs ta{};
         ta.w = w; ta.off = o; ta.d = d; ta.team_w = h->team_w; ta.team_fc3 = h->team_fc3; ta.wI0 = h->wI0; ta.u1 = h->u1;
         ta.tabREC = tREC; ta.tabCOND = nullptr; ta.tabC2 = tC2; ta.tabC3 = tC3; ta.tabC4 = tC4;
-        ta.rows = h->rows_dev; ta.n_rows = rows; ta.n_teams = h->n_teams; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
+        ta.rows = h->rows_dev; ta.sched = h->sched_dev; ta.n_slots = n_slots; ta.ragged = snake; ta.n_rows = rows; ta.n_teams = h->n_teams; ta.T = T; ta.total_len = a.total_len; ta.steps = steps;
         ta.seg0 = 0; ta.seg_len = steps; ta.state = nullptr;
         ta.noise_mode = a.noise_mode; ta.seed = a.seed; ta.noise1 = a.noise1; ta.noise2 = a.noise2; ta.x_forced = a.x_forced; ta.x_init = a.x_init;
         ta.logits_out = a.logits_out; ta.labels_out = a.labels_out; ta.samples_out = a.samples_out;
-        ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = h->prof;
+        ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->err_dev; ta.prof = prof;
         {
             // The phase-A conditioning is streamed from HBM (8 KB per row and step).  A row is generated in segments,
             // one stream chunk + one loop launch each, sized so that the chunk (~64 MB over all rows) is still resident
@@ -566,7 +618,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             int64_t seg = ((int64_t)(64u << 20) / ((int64_t)rows * H * 4 * (int64_t)sizeof(float))) & ~(int64_t)31;
             if (seg > 16384) seg = 16384;
             if (seg < 2048) seg = 2048;
-            if (const char *e = getenv("WRNN_TEAM2_SEGMENT")) { seg = atoll(e) & ~(int64_t)31; if (seg < 32) seg = 32; }   // developer knob
+            if (opts->team2_segment > 0) { seg = (int64_t)opts->team2_segment & ~(int64_t)31; if (seg < 32) seg = 32; }
             if (seg > steps) seg = steps;
             const size_t nCOND = (size_t)rows * (size_t)seg * H * 4;
             if (nCOND > h->cond_cap) {
@@ -583,16 +635,20 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
                 h->team_state_cap = nST;
             }
             HIP_TRY(h, hipEventRecord(h->ev[1], s));  // the tables are prologue work; the stream chunks are timed with the loop
-            if (h->prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long), s));
+            if (prof) HIP_TRY(h, hipMemsetAsync(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long), s));
             ta.team_w = h->team_w; ta.tabCOND = h->cond; ta.state = h->team_state;
             h->prof_div = (double)steps * ((rows + h->n_teams - 1) / h->n_teams);
             for (int64_t t0 = 0; t0 < steps; t0 += seg) {
                 const int64_t len = steps - t0 < seg ? steps - t0 : seg;
                 HIP_TRY(h, wrnn_launch_cond_stream(tREC, w + o.ktab, h->rows_dev, h->cond, rows, T, d.HOP, a.total_len, t0, len, s));
-                HIP_TRY(h, hipMemsetAsync(h->mail, 0, mail_bytes, s));
-                HIP_TRY(h, hipMemsetAsync(h->ctl, 0, 128, s));
                 ta.seg0 = t0; ta.seg_len = len;
-                HIP_TRY(h, wrnn_launch_loop_team2(ta, s));
+                HIP_TRY(h, wrnn_team_gate_enter(h->cfg.device, s));   // see the BATCH branch
+                hipError_t le = hipMemsetAsync(h->mail, 0, mail_bytes, s);
+                if (le == hipSuccess) le = hipMemsetAsync(h->ctl, 0, 128, s);
+                if (le == hipSuccess) le = wrnn_launch_loop_team2(ta, s);
+                const hipError_t ge = wrnn_team_gate_leave(h->cfg.device, s);
+                HIP_TRY(h, le);
+                HIP_TRY(h, ge);
                 launches = (int)(t0 / seg) + 1;
             }
         }
@@ -633,18 +689,42 @@ int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out) {
     unsigned errw = 0;
     HIP_TRY(h, hipMemcpy(&errw, h->err_dev, sizeof(errw), hipMemcpyDeviceToHost));
     if (out) *out = h->last;
-    if (h->prof && (h->last.kernel == WRNN_KERNEL_TEAM2 || h->last.kernel == WRNN_KERNEL_BATCH)) {
-        unsigned long long pr[8 * WRNN_PROF_SLOTS];
-        HIP_TRY(h, hipMemcpy(pr, h->prof, sizeof(pr), hipMemcpyDeviceToHost));
-        const double n = h->prof_div > 0 ? h->prof_div : 1.0;   // steps x rows (or batches) team 0 ran
-        for (int wv = 0; wv < 8; ++wv) {
-            fprintf(stderr, "[wrnn prof] %s %d cycles/step:", h->last.kernel == WRNN_KERNEL_TEAM2 ? "team2 wg0 wave" : "batch wg0 wave", wv);
-            double tot = 0;
-            for (int i = 0; i < WRNN_PROF_SLOTS; ++i) { fprintf(stderr, " %.0f", pr[wv * WRNN_PROF_SLOTS + i] / n); tot += pr[wv * WRNN_PROF_SLOTS + i] / n; }
-            fprintf(stderr, " | total %.0f\n", tot);
-        }
-    }
+    if (errw == WRNN_DEVERR_BUSY)
+        return fail(h, WRNN_ERR_BUSY, "the team kernel's workgroups did not all become resident within its start-up wait: the GPU is shared with another "
+                                      "kernel (another process?).  Retry, or use WRNN_KERNEL_SIMPLE");
     if (errw) return fail(h, WRNN_ERR_TIMEOUT, "device-side bounded spin gave up (code %u)", errw);
+    return WRNN_OK;
+}
+
+int wrnn_phase_profile(wrnn_handle *h, int32_t enable) {
+    if (!h) return WRNN_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (enable) {
+        // the instrumented instantiations have their own register / LDS footprint: check their residency like wrnn_create does
+        int blocks = 0;
+        size_t lds = 0;
+        if (h->team_ok) {
+            hipError_t e = wrnn_team2_occupancy(h->cfg.mode, true, &blocks, &lds);
+            for (int nq = 1; nq <= 2 && e == hipSuccess && blocks >= 1; ++nq) e = wrnn_batch_occupancy(h->cfg.mode, nq, true, &blocks, &lds);
+            (void)hipGetLastError();
+            if (e != hipSuccess || blocks < 1) return fail(h, WRNN_ERR_INVALID, "the instrumented team kernels cannot be resident on this device");
+        }
+        if (!h->prof) HIP_TRY(h, hipMalloc(&h->prof, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(h->prof, 0, 8 * WRNN_PROF_SLOTS * sizeof(unsigned long long)));
+    }
+    h->prof_on = enable != 0;
+    return WRNN_OK;
+}
+
+int wrnn_phase_cycles(wrnn_handle *h, double *out) {
+    if (!h || !out) return WRNN_ERR_INVALID;
+    if (!h->prof_on || !h->prof || !h->timing_valid) return fail(h, WRNN_ERR_STATE, "no instrumented call to report (wrnn_phase_profile(h, 1), then a TEAM2 / BATCH call)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(h->ev[2]));
+    unsigned long long pr[8 * WRNN_PROF_SLOTS];
+    HIP_TRY(h, hipMemcpy(pr, h->prof, sizeof(pr), hipMemcpyDeviceToHost));
+    const double n = h->prof_div > 0 ? h->prof_div : 1.0;   // steps x rows (or batches) team 0 ran
+    for (int i = 0; i < 8 * WRNN_PROF_SLOTS; ++i) out[i] = (double)pr[i] / n;
     return WRNN_OK;
 }
 

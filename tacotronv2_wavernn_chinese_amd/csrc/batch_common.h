@@ -1,4 +1,4 @@
-// Building blocks of the batch kernel (loop_batch.hip; kept apart so that experimental schedules can share them): team / mailbox primitives, the
+// Building blocks of the batch kernel (loop_batch.hip): team / mailbox primitives, the
 // v_mfma_f32_4x4x1 loops with hand-made software pipelining, the K-phase fold, the LDS carve-up.  See loop_batch.hip for the
 // mapping these pieces implement.
 #pragma once
@@ -241,53 +241,6 @@ __device__ __forceinline__ void mfma_single(const float *w, lds_cf4p xv, f4 (&su
         sum[q] = acc[0][q];
 #pragma unroll
         for (int p = 1; p < NP; ++p) sum[q] += acc[p][q];
-    }
-}
-
-// ---- pieces of the ping-pong variant (PP, see the kernel): one row quad at a time, NQ = 1 shaped loops -----------------
-template <int V> struct IC { static constexpr int value = V; };
-
-// gh2 of the next step for one quad: acc[g] += W_hh2_g . (x3 - x2), gates r, z from the parked weights, gate n from LDS
-template <int D>
-__device__ __forceinline__ void mfma_whh2_quad(const float *wa, lds_cf4p xq_, lds_cf4p xp_, lds_cf4p wnl, f4 (&acc)[3]) {
-    f4 rq[D], rp[D], rw[D];
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) { rq[dd] = xq_[dd * 64]; rp[dd] = xp_[dd * 64]; rw[dd] = wnl[dd * 64]; }
-#pragma unroll
-    for (int S = 0; S < 8; ++S) {
-        const f4 b = rq[S % D] - rp[S % D];
-        const f4 wn = rw[S % D];
-        if (S + D < 8) { rq[S % D] = xq_[(S + D) * 64]; rp[S % D] = xp_[(S + D) * 64]; rw[S % D] = wnl[(S + D) * 64]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0] = mfma4(aget(wa[96 + 4 * S + e]), b[e], acc[0]);
-            acc[1] = mfma4(aget(wa[128 + 4 * S + e]), b[e], acc[1]);
-            acc[2] = mfma4(wn[e], b[e], acc[2]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-// fc3 slice (2 class sets of the wave, A operands from LDS) for one quad; one accumulator chain per set like the lock-step
-// 8-row loop, so that the ping-pong variant's logits are bit-equal to the lock-step kernel's
-template <int D>
-__device__ __forceinline__ void mfma_fc3_quad(lds_cf4p w3, lds_cf4p xv, f4 &s0, f4 &s1) {
-    s0 = (f4){0.f, 0.f, 0.f, 0.f};
-    s1 = (f4){0.f, 0.f, 0.f, 0.f};
-    f4 rx[D], ra[D], rb[D];
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) { rx[dd] = xv[dd * 64]; ra[dd] = w3[dd * 64]; rb[dd] = w3[(8 + dd) * 64]; }
-#pragma unroll
-    for (int S = 0; S < 8; ++S) {
-        const f4 b = rx[S % D], wa = ra[S % D], wb = rb[S % D];
-        if (S + D < 8) { rx[S % D] = xv[(S + D) * 64]; ra[S % D] = w3[(S + D) * 64]; rb[S % D] = w3[(8 + S + D) * 64]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s0 = mfma4(wa[e], b[e], s0);
-            s1 = mfma4(wb[e], b[e], s1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

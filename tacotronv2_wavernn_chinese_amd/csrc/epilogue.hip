@@ -44,6 +44,28 @@ epilogue_kernel(const float *__restrict__ samples, const int32_t *__restrict__ l
     out[n] = v;
 }
 
+// wrnn_epilogue_rows: every row an independent unbatched utterance, grid (ceil(out_stride / 256), rows)
+__global__ void __launch_bounds__(256)
+epilogue_rows_kernel(const float *__restrict__ samples, const int32_t *__restrict__ labels, const double *__restrict__ dec,
+                     const double *__restrict__ tail, long steps, long wave_len, long tail_len, const int32_t *__restrict__ frames,
+                     int hop, double *__restrict__ out, long out_stride) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= out_stride) return;
+    long wl = wave_len;
+    if (frames) {
+        wl = ((long)frames[r] - 1) * hop;
+        if (wl > wave_len) wl = wave_len;
+    }
+    double v = 0.0;
+    if (wl >= tail_len && n < wl) {
+        const size_t i = (size_t)r * (size_t)steps + (size_t)n;
+        v = dec ? dec[labels[i]] : (double)samples[i];                                     // (:243-248), row r as :253 takes row 0
+        if (n >= wl - tail_len) v = __dmul_rn(v, tail[n - (wl - tail_len)]);               // (:255-258)
+    }
+    out[(size_t)r * (size_t)out_stride + (size_t)n] = v;
+}
+
 // np.linspace(start, stop, num) in float64: arange(num) * step + start, last element = stop
 #pragma clang fp contract(off)
 void np_linspace(double start, double stop, long num, double *y) {
@@ -87,6 +109,46 @@ extern "C" int wrnn_epilogue_tables(int32_t n_classes, int32_t overlap, int32_t 
     return WRNN_OK;
 }
 
+// device copy of the host tables [dec NC | fade_in ov | fade_out ov | tail 20*hop] for overlap `ov`, rebuilt when ov changes
+static const char *epilogue_tables_on_device(wrnn_handle *h, long ov) {
+    const int NC = h->d.NC;
+    const long tail_len = 20L * h->d.HOP;
+    if (h->epi_overlap == ov && h->epi_tab) return nullptr;
+    std::vector<double> tab((size_t)NC + 2 * (size_t)ov + (size_t)tail_len, 0.0);
+    double *dec = tab.data(), *fin = dec + NC, *fout = fin + ov, *tail = fout + ov;
+    wrnn_epilogue_tables(NC, (int32_t)ov, h->d.HOP, dec, fin, fout, tail);
+    if (h->epi_tab) { (void)hipFree(h->epi_tab); h->epi_tab = nullptr; }
+    if (hipMalloc(&h->epi_tab, tab.size() * sizeof(double)) != hipSuccess) return "wrnn_epilogue: hipMalloc failed";
+    if (hipMemcpy(h->epi_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return "wrnn_epilogue: table upload failed";
+    h->epi_overlap = ov;
+    return nullptr;
+}
+
+extern "C" int wrnn_epilogue_rows(wrnn_handle *h, const float *samples_dev, const int32_t *labels_dev, int32_t rows, int64_t steps,
+                                  int32_t mu_law, int64_t wave_len, const int32_t *frames_dev, double *wave_out_dev, int64_t out_stride,
+                                  void *stream) {
+    if (!h) return WRNN_ERR_INVALID;
+    auto fail = [&](int code, const char *msg) { h->err = msg; return code; };
+    if (!samples_dev || !wave_out_dev || rows < 1 || steps < 1) return fail(WRNN_ERR_INVALID, "wrnn_epilogue_rows: null buffer or empty input");
+    const WrnnDims &d = h->d;
+    const bool decode = mu_law && d.mode == WRNN_MODE_RAW;   // MOL forces mu_law off (:174)
+    if (decode && !labels_dev) return fail(WRNN_ERR_INVALID, "wrnn_epilogue_rows: mu-law decode needs the labels of the RAW loop");
+    const long tail_len = 20L * d.HOP;
+    if (wave_len < tail_len) return fail(WRNN_ERR_INVALID, "wrnn_epilogue_rows: wave_len shorter than the 20-hop fade-out (the reference raises ValueError for T < 21)");
+    if (wave_len > steps) return fail(WRNN_ERR_INVALID, "wrnn_epilogue_rows: wave_len exceeds the generated length");
+    if (out_stride < wave_len) return fail(WRNN_ERR_INVALID, "wrnn_epilogue_rows: out_stride shorter than wave_len");
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(WRNN_ERR_HIP, "wrnn_epilogue_rows: hipSetDevice failed");
+    const long ov = h->epi_tab ? h->epi_overlap : 0;   // any overlap's table set holds dec and tail
+    if (const char *e = epilogue_tables_on_device(h, ov)) return fail(WRNN_ERR_HIP, e);
+    const double *dec = h->epi_tab, *tail = dec + d.NC + 2 * ov;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(epilogue_rows_kernel, dim3((unsigned)((out_stride + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                       samples_dev, labels_dev, decode ? dec : nullptr, tail, (long)steps, (long)wave_len, tail_len, frames_dev, d.HOP,
+                       wave_out_dev, (long)out_stride);
+    if (hipGetLastError() != hipSuccess) return fail(WRNN_ERR_HIP, "wrnn_epilogue_rows: launch failed");
+    return WRNN_OK;
+}
+
 extern "C" int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int32_t *labels_dev, int32_t rows, int64_t steps,
                              int32_t batched, int32_t target, int32_t overlap, int32_t mu_law, int64_t wave_len,
                              double *wave_out_dev, void *stream) {
@@ -108,19 +170,9 @@ extern "C" int wrnn_epilogue(wrnn_handle *h, const float *samples_dev, const int
     }
     hipStream_t s = (hipStream_t)stream;
     if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(WRNN_ERR_HIP, "wrnn_epilogue: hipSetDevice failed");
-    // ---- host tables: [dec NC | fade_in ov | fade_out ov | tail 20*hop] ----
     const int NC = d.NC;
     const long ov = batched ? overlap : 0;
-    if (h->epi_overlap != ov || !h->epi_tab) {
-        std::vector<double> tab((size_t)NC + 2 * (size_t)ov + (size_t)tail_len, 0.0);
-        double *dec = tab.data(), *fin = dec + NC, *fout = fin + ov, *tail = fout + ov;
-        wrnn_epilogue_tables(NC, (int32_t)ov, d.HOP, dec, fin, fout, tail);
-        if (h->epi_tab) { (void)hipFree(h->epi_tab); h->epi_tab = nullptr; }
-        if (hipMalloc(&h->epi_tab, tab.size() * sizeof(double)) != hipSuccess) return fail(WRNN_ERR_HIP, "wrnn_epilogue: hipMalloc failed");
-        if (hipMemcpy(h->epi_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-            return fail(WRNN_ERR_HIP, "wrnn_epilogue: table upload failed");
-        h->epi_overlap = ov;
-    }
+    if (const char *e = epilogue_tables_on_device(h, ov)) return fail(WRNN_ERR_HIP, e);
     const double *dec = h->epi_tab, *fin = dec + NC, *fout = fin + ov, *tail = fout + ov;
     (void)hipGetLastError();
     hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)((wave_len + 255) / 256)), dim3(256), 0, s, samples_dev, labels_dev,

@@ -35,7 +35,7 @@
 // R x 512 granules in the order the B operand wants them in LDS, read with 16-byte sc1 loads (two granules each).
 #include "batch_common.h"
 
-template <int MODE, int NQ, bool PROF, bool PP = false>
+template <int MODE, int NQ, bool PROF>
 __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a) {
     typedef Lay<NQ> L;
     constexpr int R = L::R, NM = L::NM;
@@ -69,6 +69,16 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 slot1 = __hip_atomic_load(&a.ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (slot1) break;
             }
+        }
+        // co-residency checked, not assumed (see loop_team2.hip): all 32 workgroups of the XCD must have arrived
+        if (slot1 && rank < TB_WGS) {
+            unsigned arrived = 0;
+            for (unsigned spins = 0; spins < WRNN_ARRIVE_POLLS; ++spins) {
+                arrived = __hip_atomic_load(&a.ctl[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived >= TB_WGS) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (arrived < TB_WGS) { atomicCAS(a.err, 0u, WRNN_DEVERR_BUSY); slot1 = 0; }
         }
         misc_i[M_TEAM] = slot1 ? (int)slot1 - 1 : 1 << 20;
         misc_i[M_RANK] = (int)rank;
@@ -133,11 +143,16 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
     u64 prof_acc[WRNN_PROF_SLOTS] = {0};
     u64 prof_last = 0;
 
-    for (int batch = team; batch < n_batches; batch += a.n_teams) {
-        const int row_raw = batch * a.rpb + rb;
-        const bool row_ok = rb < a.rpb && row_raw < a.n_rows;
-        const int row = row_ok ? row_raw : a.n_rows - 1;     // spare slots of a batch re-run the last row (outputs masked)
+    // schedule: batch b = slots [b * rpb, (b + 1) * rpb) of a.order; the batches are dealt to the teams round-robin, or in snake
+    // order on a ragged batch (a.order is longest-first, so batches hold rows of similar length and the teams' sums even out)
+    for (int pass = 0; pass * a.n_teams < n_batches; ++pass) {
+        const int batch = pass * a.n_teams + ((a.snake && (pass & 1)) ? a.n_teams - 1 - team : team);
+        if (batch >= n_batches) continue;
+        const int slot_raw = batch * a.rpb + rb;
+        const bool row_ok = rb < a.rpb && slot_raw < a.n_rows;
+        const int row = a.order[row_ok ? slot_raw : a.n_rows - 1];     // spare slots of a batch re-run the last row (outputs masked)
         const WrnnRow rw = a.rows[row];
+        const int64_t bsteps = a.rows[a.order[batch * a.rpb]].steps;   // the batch runs for its first (longest) row's steps
         const float *recb = a.tabREC32 + (size_t)rw.utt * (T + 1) * 512 * 32 + (size_t)unit * 32;
         const float *ktab = a.w + a.off.ktab;
 
@@ -152,8 +167,18 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
         int nfi = (int)(rw.start / HOP), nph = (int)(rw.start - (int64_t)nfi * HOP);   // frame / phase of the step being prepared
         int cst_frame = -1000000, pend_frame = -1;
         if (tid < R) {
-            const int r0 = batch * a.rpb + tid;
-            xn[tid] = (a.x_init && tid < a.rpb && r0 < a.n_rows) ? a.x_init[r0] : 0.0f;
+            const int s0 = batch * a.rpb + tid;
+            xn[tid] = (a.x_init && tid < a.rpb && s0 < a.n_rows) ? a.x_init[a.order[s0]] : 0.0f;
+        }
+        // rows this wave finishes (exchange 5): wave wl owns batch rows wl, wl + 4
+        int frow[NQ];
+        int fsteps[NQ];
+#pragma unroll
+        for (int bi = 0; bi < NQ; ++bi) {
+            const int brow = wl + 4 * bi, s0 = batch * a.rpb + brow;
+            const bool rok = brow < a.rpb && s0 < a.n_rows;
+            frow[bi] = a.order[rok ? s0 : a.n_rows - 1];
+            fsteps[bi] = rok ? a.rows[frow[bi]].steps : 0;   // 0 = masked
         }
 
         // conditioning {cI, v_r, v_z, v_n} of step ts for (unit, row): record + 5-tap upsampling (prologue.hip)
@@ -220,379 +245,16 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     const u2v so = __builtin_amdgcn_permlane32_swap(__float_as_uint(give_o), __float_as_uint(give_o), false, false);
                     const float recv_e = __uint_as_float(upper ? se.x : se.y), recv_o = __uint_as_float(upper ? so.x : so.y);
                     nz0 = upper ? recv_e : mine_e; nz1 = upper ? mine_e : recv_e;
-                    if constexpr (PP) {   // the odd step's pair waits in AGPRs (the lock-step kernel keeps it in 8 bytes of scratch)
-                        apark(pz0, upper ? recv_o : mine_o); apark(pz1, upper ? mine_o : recv_o);
-                    } else {
-                        pz0 = upper ? recv_o : mine_o; pz1 = upper ? mine_o : recv_o;
-                    }
-                } else { nz0 = aget(pz0); nz1 = aget(pz1); }
+                    pz0 = upper ? recv_o : mine_o; pz1 = upper ? mine_o : recv_o;
+                } else { nz0 = pz0; nz1 = pz1; }
             } else { nz0 = 0.f; nz1 = 0.f; }
         };
         cond_fetch(0);
         cond_combine();
-        if (a.steps > 1) cond_fetch(1);
+        if (bsteps > 1) cond_fetch(1);
         __syncthreads();
 
-        if constexpr (PP) {
-            // ================= ping-pong variant (WRNN_BATCH_PP=1, 8 rows per team; opt-in until measured) =================
-            // The two row quads of the team run half a window apart: while quad a computes a phase, the all-gather of quad b's
-            // previous phase is in flight (requested before the MFMAs, looked at after them), and vice versa -- an exchange is then
-            // waited for one compute phase after it was published, not right behind the publish.  10 half-windows per step:
-            //   1: A(a) | race(b, t-1)   2: A(b), conditioning of t+1 | x2,h1'(a)   3: B(a) + W_hh1(a) | x2,h1'(b)   4: B(b) + W_hh1(b) | x3(a)
-            //   5: fc1(a) + W_hh2(a) | x3(b)   6: fc1(b) + W_hh2(b) | f1(a)   7: fc2(a), noise | f1(b)   8: fc2(b) | f2(a)
-            //   9: fc3(a) + race | f2(b)      10: fc3(b) + race | race(a, t)
-            // Per-thread state is unchanged (a thread is one (unit, row) pair of ONE quad: my_rq); the MFMA phases use all lanes
-            // for the quad at hand and the lanes of that quad keep the result.  Every loop adds in the order of the lock-step
-            // 8-row loops, so logits and labels are bit-equal to the lock-step kernel's.
-            static_assert(!PP || NQ == 2, "the ping-pong variant alternates two row quads");
-            constexpr unsigned QB = 4u * 4096u;   // bytes from quad 0's to quad 1's slices inside a published region
-            constexpr int QV = 512;               // the same inside an activation vector in LDS, in f4 ([rq][S][lane])
-            auto put = [&](auto qc, auto bc, const u4v (&gv)[4]) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value, buf = decltype(bc)::value;   // buf: 0 = P, 1 = Q, 2 = H1
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    gdst[(buf * L::VEC + q * 2048 + m * 64) / 2] = (f2v){__uint_as_float(gv[m].x), __uint_as_float(gv[m].z)};
-            };
-            // phase A of quad q: I + GRU1 for the quad's (unit, row) pairs (:208-212), publish x2 and h1'
-            auto ppA = [&](auto qc, unsigned ep, unsigned pr) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
-                if (my_rq == q) {
-                    const float xprev = xn[rb];
-                    const float xin = fmaf(cst[C_A0 * 256], xprev, cd.x);
-                    const float rg = sigmoid_fast(fmaf(cst[C_A1 * 256], xprev, cd.y) + gh1r);
-                    const float zg = sigmoid_fast(fmaf(cst[C_A2 * 256], xprev, cd.z) + gh1z);
-                    const float ng = tanh_fast(fmaf(cst[C_A3 * 256], xprev, cd.w) + rg * gh1n);
-                    h1 = (1.0f - zg) * ng + zg * h1;
-                    x2own = xin + h1;
-                    if (primary) {
-                        st_granule(mail, L::G_X2 + pr * L::RG + mb_own, ep, __float_as_uint(x2own));
-                        st_granule(mail, L::G_H1 + pr * L::RG + mb_own, ep, __float_as_uint(h1));
-                    }
-                }
-            };
-            // phase B of quad q (GRU2, :213-216), publish x3; then gh1 of the next step = W_hh1 . h1' + b_hh1
-            auto ppB = [&](auto qc, unsigned ep, unsigned pr) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
-                {
-                    f4 acc[3][1];
-#pragma unroll
-                    for (int gt = 0; gt < 3; ++gt) acc[gt][0] = (f4){0.f, 0.f, 0.f, 0.f};
-                    mfma_gates<1, 3, false, 2>(wv, vP + q * QV, acc, NoMid());
-                    const float tr = fold_kp(acc[0][0]), tz = fold_kp(acc[1][0]), tn = fold_kp(acc[2][0]);
-                    if (my_rq == q) {
-                        const float rg = sigmoid_fast((tr + c2.x) + gh2r);
-                        const float zg = sigmoid_fast((tz + c2.y) + gh2z);
-                        const float ng = tanh_fast((tn + c2.z) + rg * gh2n);
-                        h2 = (1.0f - zg) * ng + zg * h2;
-                        const float x3 = x2own + h2;
-                        if (primary) st_granule(mail, L::G_X3 + pr * L::RG + mb_own, ep, __float_as_uint(x3));
-                    }
-                }
-                {
-                    f4 acc[3][1];
-#pragma unroll
-                    for (int gt = 0; gt < 3; ++gt) acc[gt][0] = (f4){0.f, 0.f, 0.f, 0.f};
-                    mfma_gates<1, 3, true, 2>(wa, vH1 + q * QV, acc, NoMid());
-                    const float fr = fold_kp(acc[0][0]), fz = fold_kp(acc[1][0]), fn = fold_kp(acc[2][0]);
-                    if (my_rq == q) { gh1r = fr + cst[C_H1R * 256]; gh1z = fz + cst[C_H1Z * 256]; gh1n = fn + cst[C_H1N * 256]; }
-                }
-            };
-            // phase C of quad q (fc1, :217-218), publish; then gh2 of the next step = W_hh2 . (x3 - x2) + b_hh2
-            auto ppC = [&](auto qc, unsigned ep, unsigned pr) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
-                {
-                    f4 sum[1];
-                    mfma_single<1, 2, true, 4>(wa + 160, vQ + q * QV, sum);
-                    const float sv = fold_kp(sum[0]);
-                    if (my_rq == q && primary) st_granule(mail, L::G_F1 + pr * L::RG + mb_own, ep, __float_as_uint(fmaxf(sv + c2.w, 0.0f)));
-                }
-                {
-                    f4 acc[3];
-#pragma unroll
-                    for (int gt = 0; gt < 3; ++gt) acc[gt] = (f4){0.f, 0.f, 0.f, 0.f};
-                    mfma_whh2_quad<2>(wa, vQ + q * QV, vP + q * QV, wnl, acc);
-                    const float fr = fold_kp(acc[0]), fz = fold_kp(acc[1]), fn = fold_kp(acc[2]);
-                    if (my_rq == q) { gh2r = fr + cst[C_H2R * 256]; gh2z = fz + cst[C_H2Z * 256]; gh2n = fn + cst[C_H2N * 256]; }
-                }
-            };
-            // phase D of quad q (fc2, :220-221), publish
-            auto ppD = [&](auto qc, unsigned ep, unsigned pr) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
-                f4 sum[1];
-                mfma_single<1, 2, true, 4>(wa + 192, vH1 + q * QV, sum);
-                const float sv = fold_kp(sum[0]);
-                if (my_rq == q && primary) st_granule(mail, L::G_F2 + pr * L::RG + mb_own, ep, __float_as_uint(fmaxf(sv + c4, 0.0f)));
-            };
-            // phase E of quad q (fc3 :223, the race inside the wave :231-235), publish the wave's candidates; `late` runs between
-            // the MFMAs and the fold (the point where the other quad's exchange is requested)
-            auto ppE = [&](auto qc, int64_t tt, unsigned ep, unsigned pr, auto late) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
-                float lg0 = 0.f, lg1 = 0.f;
-                f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
-                if (wg_has_fc3) mfma_fc3_quad<2>(w3, vP + q * QV, s0, s1);
-                late();
-                if (wg_has_fc3) {
-                    lg0 = fold_kp(s0) + cst[C_B30 * 256];
-                    lg1 = fold_kp(s1) + cst[C_B31 * 256];
-                    if (a.logits_out && primary && row_ok && my_rq == q) {
-                        float *lo = a.logits_out + ((size_t)tt * a.n_rows + row) * NC;
-                        if (cls0 < NC) lo[cls0] = lg0;
-                        if (cls0 + 4 < NC) lo[cls0 + 4] = lg1;
-                    }
-                }
-                if (MODE == WRNN_MODE_RAW) {
-                    float v = cls0 < NC ? lg0 + nz0 : -INFINITY;
-                    int k = cls0;
-                    const float v1 = cls0 + 4 < NC ? lg1 + nz1 : -INFINITY;
-                    if (v1 > v) { v = v1; k = cls0 + 4; }
-                    {
-                        const u2v pv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                        const u2v pk = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
-                        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
-                        const int ka = (int)pk.x, kb = (int)pk.y;
-                        const bool tb = vb > va || (vb == va && kb < ka);
-                        v = tb ? vb : va; k = tb ? kb : ka;
-                    }
-                    {
-                        const u2v pv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                        const u2v pk = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
-                        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
-                        const int ka = (int)pk.x, kb = (int)pk.y;
-                        const bool tb = vb > va || (vb == va && kb < ka);
-                        v = tb ? vb : va; k = tb ? kb : ka;
-                    }
-                    if (primary && rho == 0 && my_rq == q)
-                        st_granule(mail, L::G_PR + pr * L::PRG + (unsigned)rb * 128u + (unsigned)(g * 4 + wl),
-                                   (ep << 10) | (unsigned)(k & 1023), __float_as_uint(v));
-                } else {
-                    if (wg_has_fc3 && primary && my_rq == q) {
-                        if (cls0 < NC) st_granule(mail, L::G_PR + pr * L::PRG + (unsigned)rb * 128u + (unsigned)cls0, ep, __float_as_uint(lg0));
-                        if (cls0 + 4 < NC) st_granule(mail, L::G_PR + pr * L::PRG + (unsigned)rb * 128u + (unsigned)(cls0 + 4), ep, __float_as_uint(lg1));
-                    }
-                }
-            };
-            // exchange 5 for quad q: wave w finishes batch row w + 4 q of step tt (request | wait, reduce, x_new, outputs)
-            auto race_issue = [&](auto qc, unsigned pr) __attribute__((always_inline)) -> u4v {
-                constexpr int q = decltype(qc)::value;
-                if (MODE != WRNN_MODE_RAW) return (u4v){0u, 0u, 0u, 0u};
-                return ld_pair(mrs, (unsigned)lane * 16u, (L::G_PR + pr * L::PRG + (unsigned)(wl + 4 * q) * 128u) * 8u);
-            };
-            auto race_finish = [&](auto qc, int64_t tt, unsigned ep, unsigned pr, u4v gq) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
-                const int brow = wl + 4 * q;
-                const int rrow_raw = batch * a.rpb + brow;
-                const bool rok = brow < a.rpb && rrow_raw < a.n_rows;
-                const int rrow = rok ? rrow_raw : a.n_rows - 1;
-                float x_new;
-                int lab;
-                if (MODE == WRNN_MODE_RAW) {
-                    const unsigned tg = ep & 0x3fffffu;
-                    unsigned spins = 0;
-                    while (!dead && !__all((gq.y >> 10) == tg && (gq.w >> 10) == tg)) {
-                        if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 26u); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        gq = ld_pair(mrs, (unsigned)lane * 16u, (L::G_PR + pr * L::PRG + (unsigned)brow * 128u) * 8u);
-                    }
-                    const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
-                    const bool pb = vb > va;   // equal scores: the lower slot = the lower class range wins
-                    const float best = pb ? vb : va;
-                    const int besti = (int)((pb ? gq.w : gq.y) & 1023u);
-                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
-                    const u64 ball = __ballot(best == mx);
-                    const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
-                    lab = __builtin_amdgcn_readlane(besti, src);
-                    x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
-                } else {
-                    // sample_from_discretized_mix_logistic (distribution.py:87-123) for batch row `brow`
-                    const int nr = NC / 3;
-                    float nzv = 0.0f;
-                    if (lane <= nr) {
-                        float u;
-                        if (a.noise_mode == WRNN_NOISE_INJECTED)
-                            u = lane < nr ? a.noise1[((size_t)tt * a.n_rows + rrow) * nr + lane] : a.noise2[(size_t)tt * a.n_rows + rrow];
-                        else
-                            u = 1e-5f + wrnn_uniform(a.seed, (uint64_t)tt, (uint32_t)rrow, (uint32_t)lane) * (1.0f - 2e-5f);
-                        nzv = lane < nr ? -logf(-logf(u)) : logf(u) - logf(1.0f - u);
-                    }
-                    float mylg = 0.0f;
-                    {
-                        const u64 *gp = mail + L::G_PR + pr * L::PRG + (unsigned)brow * 128u + (unsigned)(lane < NC ? lane : 0);
-                        u64 gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        unsigned spins = 0;
-                        while (!dead && !__all((unsigned)(gv >> 32) == ep)) {
-                            if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 27u); break; }
-                            __builtin_amdgcn_s_sleep(1);
-                            gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        mylg = __uint_as_float((unsigned)gv);
-                    }
-                    const float v = lane < nr ? mylg + nzv : -INFINITY;
-                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(v)), 63));
-                    const u64 ball = __ballot(v == mx);
-                    const int km = (int)__builtin_ctzll(ball ? ball : 1ull);
-                    const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylg), nr + km));
-                    const float ls = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylg), 2 * nr + km)), -32.23619130191664f);
-                    const float nlog = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nzv), nr));
-                    x_new = fminf(fmaxf(mean + expf(ls) * nlog, -1.0f), 1.0f);
-                    lab = km;
-                }
-                if (lane == 0) {
-                    xn[brow] = a.x_forced ? a.x_forced[(size_t)tt * a.n_rows + rrow] : x_new;   // (:237)
-                    if (g == 0 && rok) {
-                        if (a.labels_out) a.labels_out[(size_t)rrow * a.steps + tt] = lab;
-                        a.samples_out[(size_t)rrow * a.steps + tt] = x_new;
-                    }
-                }
-            };
-
-            for (int64_t t = 0; t < a.steps; ++t) {
-                ++epoch;
-                const unsigned par = epoch & 1u;
-                if (PROF) prof_last = __builtin_readcyclecounter();
-                // ---- 1: A(a) | race(b) of the previous step
-                ppA(IC<0>(), epoch, par);
-                PB(0);
-                if (t > 0) {
-                    const u4v gq = race_issue(IC<1>(), par ^ 1u);
-                    race_finish(IC<1>(), t - 1, epoch - 1u, par ^ 1u, gq);
-                }
-                PB(1);
-                __syncthreads();
-                PB(2);
-                // ---- 2: A(b), constants of this step's frame, conditioning of the next step | x2, h1' of quad a
-                {
-                    u4v gx[2][4];
-                    const unsigned offs[2] = {(L::G_X2 + par * L::RG) * 8u, (L::G_H1 + par * L::RG) * 8u};
-                    gather_issue<4, 2>(mrs, gvoff, offs, gx);
-                    ppA(IC<1>(), epoch, par);
-                    frame_consts();
-                    if (t + 1 < a.steps) {
-                        cond_combine();
-                        if (t + 2 < a.steps) cond_fetch(t + 2);
-                    }
-                    PB(3);
-                    gather_vecs<4, 2, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 21u);
-                    put(IC<0>(), IC<0>(), gx[0]);
-                    put(IC<0>(), IC<2>(), gx[1]);
-                    PB(4);
-                }
-                __syncthreads();
-                PB(5);
-                // ---- 3: B(a) + W_hh1(a) | x2, h1' of quad b
-                {
-                    u4v gx[2][4];
-                    const unsigned offs[2] = {(L::G_X2 + par * L::RG) * 8u + QB, (L::G_H1 + par * L::RG) * 8u + QB};
-                    gather_issue<4, 2>(mrs, gvoff, offs, gx);
-                    ppB(IC<0>(), epoch, par);
-                    PB(6);
-                    gather_vecs<4, 2, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
-                    put(IC<1>(), IC<0>(), gx[0]);
-                    put(IC<1>(), IC<2>(), gx[1]);
-                    PB(7);
-                }
-                __syncthreads();
-                PB(8);
-                // ---- 4: B(b) + W_hh1(b) | x3 of quad a
-                {
-                    u4v gx[1][4];
-                    const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u};
-                    gather_issue<4, 1>(mrs, gvoff, offs, gx);
-                    ppB(IC<1>(), epoch, par);
-                    PB(9);
-                    gather_vecs<4, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 23u);
-                    put(IC<0>(), IC<1>(), gx[0]);
-                    PB(10);
-                }
-                __syncthreads();
-                PB(11);
-                // ---- 5: fc1(a) + W_hh2(a) | x3 of quad b
-                {
-                    u4v gx[1][4];
-                    const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u + QB};
-                    gather_issue<4, 1>(mrs, gvoff, offs, gx);
-                    ppC(IC<0>(), epoch, par);
-                    PB(12);
-                    gather_vecs<4, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 23u);
-                    put(IC<1>(), IC<1>(), gx[0]);
-                    PB(13);
-                }
-                __syncthreads();
-                PB(14);
-                // ---- 6: fc1(b) + W_hh2(b) | fc1 outputs of quad a
-                {
-                    u4v gx[1][4];
-                    const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u};
-                    gather_issue<4, 1>(mrs, gvoff, offs, gx);
-                    ppC(IC<1>(), epoch, par);
-                    PB(15);
-                    gather_vecs<4, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 24u);
-                    put(IC<0>(), IC<2>(), gx[0]);
-                    PB(16);
-                }
-                __syncthreads();
-                PB(17);
-                // ---- 7: fc2(a), sampling noise of this step | fc1 outputs of quad b
-                {
-                    u4v gx[1][4];
-                    const unsigned offs[1] = {(L::G_F1 + par * L::RG) * 8u + QB};
-                    gather_issue<4, 1>(mrs, gvoff, offs, gx);
-                    ppD(IC<0>(), epoch, par);
-                    prep_noise(t);
-                    PB(18);
-                    gather_vecs<4, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 24u);
-                    put(IC<1>(), IC<2>(), gx[0]);
-                    PB(19);
-                }
-                __syncthreads();
-                PB(20);
-                // ---- 8: fc2(b) | fc2 outputs of quad a
-                {
-                    u4v gx[1][4];
-                    const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u};
-                    gather_issue<4, 1>(mrs, gvoff, offs, gx);
-                    ppD(IC<1>(), epoch, par);
-                    PB(21);
-                    gather_vecs<4, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 25u);
-                    put(IC<0>(), IC<0>(), gx[0]);
-                    PB(22);
-                }
-                __syncthreads();
-                PB(23);
-                // ---- 9: fc3(a) + race | fc2 outputs of quad b (published late in half-window 8: requested after the fc3 MFMAs)
-                {
-                    u4v gx[1][4];
-                    const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u + QB};
-                    ppE(IC<0>(), t, epoch, par, [&]() __attribute__((always_inline)) { gather_issue<4, 1>(mrs, gvoff, offs, gx); });
-                    PB(24);
-                    gather_vecs<4, 1, true>(mrs, gvoff, offs, epoch, gx, dead, a.err, 25u);
-                    put(IC<1>(), IC<0>(), gx[0]);
-                    PB(25);
-                }
-                __syncthreads();
-                PB(26);
-                // ---- 10: fc3(b) + race | race candidates of quad a
-                {
-                    u4v gq = (u4v){0u, 0u, 0u, 0u};
-                    ppE(IC<1>(), t, epoch, par, [&]() __attribute__((always_inline)) { gq = race_issue(IC<0>(), par); });
-                    PB(27);
-                    race_finish(IC<0>(), t, epoch, par, gq);
-                    PB(28);
-                }
-                __syncthreads();
-                PB(29);
-                if ((t & 63) == 63) {   // bounded-spin bail-out, checked workgroup-wide every 64 steps
-                    if (dead && lane == 0) misc_i[M_DEAD] = 1;
-                    __syncthreads();
-                    if (misc_i[M_DEAD]) return;
-                }
-            }
-            if (a.steps > 0) {   // quad b's last step
-                const unsigned par = epoch & 1u;
-                const u4v gq = race_issue(IC<1>(), par);
-                race_finish(IC<1>(), a.steps - 1, epoch, par, gq);
-            }
-        } else
-        for (int64_t t = 0; t < a.steps; ++t) {
+        for (int64_t t = 0; t < bsteps; ++t) {
             ++epoch;
             const unsigned par = epoch & 1u;
             if (PROF) prof_last = __builtin_readcyclecounter();
@@ -793,9 +455,9 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             // ================= window 5: conditioning of the next step | phase E (fc3 :223 + sampler :225-237) | race =================
             // (the record loads are issued here, a whole window after the last publish: a wait on them directly behind a
             // granule store also waits for that store's acknowledgement -- stores count in vmcnt on gfx9 -- measured 2 281 cycles)
-            if (t + 1 < a.steps) {
+            if (t + 1 < bsteps) {
                 cond_combine();                            // step t + 1 from what was requested a step ago
-                if (t + 2 < a.steps) cond_fetch(t + 2);    // lands during the next step
+                if (t + 2 < bsteps) cond_fetch(t + 2);     // lands during the next step
             }
             PB(17);  // conditioning of the next step
             {
@@ -846,7 +508,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                         if (q == 0 || my_rq == q) { lg0 = f0; lg1 = f1; }
                     }
                     lg0 += cst[C_B30 * 256]; lg1 += cst[C_B31 * 256];
-                    if (a.logits_out && primary && row_ok) {
+                    if (a.logits_out && primary && row_ok && t < rw.steps) {
                         float *lo = a.logits_out + ((size_t)t * a.n_rows + row) * NC;
                         if (cls0 < NC) lo[cls0] = lg0;
                         if (cls0 + 4 < NC) lo[cls0 + 4] = lg1;
@@ -911,9 +573,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 #pragma unroll
             for (int bi = 0; bi < NQ; ++bi) {
                 const int brow = wl + 4 * bi;
-                const int rrow_raw = batch * a.rpb + brow;
-                const bool rok = brow < a.rpb && rrow_raw < a.n_rows;
-                const int rrow = rok ? rrow_raw : a.n_rows - 1;
+                const int rrow = frow[bi];
+                const bool rok = t < fsteps[bi];   // a real row that has not reached its own length (ragged batch)
                 float x_new;
                 int lab;
                 if (MODE == WRNN_MODE_RAW) {
@@ -985,40 +646,41 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
     }
 }
 
-template <int MODE, int NQ, bool PP>
+template <int MODE, int NQ>
 static hipError_t launch_one(const WrnnBatchArgs &a, hipStream_t s) {
     const size_t lds = (size_t)Lay<NQ>::L_TOTAL * sizeof(float);
     hipError_t e;
     if (a.prof) {
-        e = hipFuncSetAttribute((const void *)loop_batch_kernel<MODE, NQ, true, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void *)loop_batch_kernel<MODE, NQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((loop_batch_kernel<MODE, NQ, true, PP>), dim3(a.n_teams * TB_WGS), dim3(TB_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_batch_kernel<MODE, NQ, true>), dim3(a.n_teams * TB_WGS), dim3(TB_THREADS), lds, s, a);
     } else {
-        e = hipFuncSetAttribute((const void *)loop_batch_kernel<MODE, NQ, false, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void *)loop_batch_kernel<MODE, NQ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((loop_batch_kernel<MODE, NQ, false, PP>), dim3(a.n_teams * TB_WGS), dim3(TB_THREADS), lds, s, a);
+        hipLaunchKernelGGL((loop_batch_kernel<MODE, NQ, false>), dim3(a.n_teams * TB_WGS), dim3(TB_THREADS), lds, s, a);
     }
     return hipGetLastError();
 }
 
-// a.nq = 1 (4 rows per team) or 2 (8 rows); a.variant bit 0 = the ping-pong schedule (8 rows only)
+// a.nq = 1 (4 rows per team) or 2 (8 rows)
 hipError_t wrnn_launch_loop_batch(const WrnnBatchArgs &a, hipStream_t s) {
     (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
-    const bool pp = (a.variant & 1) != 0 && a.nq == 2;
-    if (a.d.mode == WRNN_MODE_RAW) {
-        if (pp) return launch_one<WRNN_MODE_RAW, 2, true>(a, s);
-        return a.nq == 2 ? launch_one<WRNN_MODE_RAW, 2, false>(a, s) : launch_one<WRNN_MODE_RAW, 1, false>(a, s);
-    }
-    if (pp) return launch_one<WRNN_MODE_MOL, 2, true>(a, s);
-    return a.nq == 2 ? launch_one<WRNN_MODE_MOL, 2, false>(a, s) : launch_one<WRNN_MODE_MOL, 1, false>(a, s);
+    if (a.d.mode == WRNN_MODE_RAW) return a.nq == 2 ? launch_one<WRNN_MODE_RAW, 2>(a, s) : launch_one<WRNN_MODE_RAW, 1>(a, s);
+    return a.nq == 2 ? launch_one<WRNN_MODE_MOL, 2>(a, s) : launch_one<WRNN_MODE_MOL, 1>(a, s);
 }
 
-// co-residency facts for wrnn_create's check: LDS bytes and the occupancy the runtime reports for the kernel
-hipError_t wrnn_batch_occupancy(int nq, int *blocks_per_cu, size_t *lds_bytes) {
-    const size_t lds = (size_t)(nq == 2 ? Lay<2>::L_TOTAL : Lay<1>::L_TOTAL) * sizeof(float);
+// co-residency facts for wrnn_create's check: LDS bytes and the occupancy the runtime reports for the instantiation that
+// (mode, nq, prof) launches
+template <int MODE, int NQ>
+static hipError_t occ_one(bool prof, int *blocks_per_cu, size_t *lds_bytes) {
+    const size_t lds = (size_t)Lay<NQ>::L_TOTAL * sizeof(float);
     *lds_bytes = lds;
-    const void *fn = nq == 2 ? (const void *)loop_batch_kernel<WRNN_MODE_RAW, 2, false> : (const void *)loop_batch_kernel<WRNN_MODE_RAW, 1, false>;
+    const void *fn = prof ? (const void *)loop_batch_kernel<MODE, NQ, true> : (const void *)loop_batch_kernel<MODE, NQ, false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, TB_THREADS, lds);
+}
+hipError_t wrnn_batch_occupancy(int mode, int nq, bool prof, int *blocks_per_cu, size_t *lds_bytes) {
+    if (mode == WRNN_MODE_RAW) return nq == 2 ? occ_one<WRNN_MODE_RAW, 2>(prof, blocks_per_cu, lds_bytes) : occ_one<WRNN_MODE_RAW, 1>(prof, blocks_per_cu, lds_bytes);
+    return nq == 2 ? occ_one<WRNN_MODE_MOL, 2>(prof, blocks_per_cu, lds_bytes) : occ_one<WRNN_MODE_MOL, 1>(prof, blocks_per_cu, lds_bytes);
 }

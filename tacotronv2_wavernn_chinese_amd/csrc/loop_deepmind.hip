@@ -292,7 +292,12 @@ int wrnn_dm_generate(wrnn_dm_handle *h, int64_t seq_len, int32_t noise_mode, uin
         DM_TRY(h, hipMemsetAsync(h->ctl, 0, 256, s));
         WrnnDmTeamArgs ta{};
         ta.base = a; ta.team_w = h->team_w; ta.team_lds = h->team_lds; ta.mail = h->mail; ta.ctl = h->ctl; ta.err = h->ctl + 32;
-        DM_TRY(h, wrnn_launch_dm_team(ta, s));
+        // team kernels of one device are ordered behind each other, whatever handle / stream launches them (wavernn_amd.h)
+        DM_TRY(h, wrnn_team_gate_enter(h->device, s));
+        const hipError_t le = wrnn_launch_dm_team(ta, s);
+        const hipError_t ge = wrnn_team_gate_leave(h->device, s);
+        DM_TRY(h, le);
+        DM_TRY(h, ge);
         return WRNN_OK;
     }
     (void)hipGetLastError();
@@ -309,6 +314,8 @@ int wrnn_dm_sync_status(wrnn_dm_handle *h, void *stream) {
     if (!h->ctl) return WRNN_OK;
     unsigned errw = 0;
     DM_TRY(h, hipMemcpy(&errw, h->ctl + 32, sizeof(errw), hipMemcpyDeviceToHost));
+    if (errw == WRNN_DEVERR_BUSY)
+        return dm_fail(h, WRNN_ERR_BUSY, "the team kernel's 32 workgroups did not all become resident: the GPU is shared with another kernel (retry, or wrnn_dm_set_kernel(h, 1))");
     if (errw) return dm_fail(h, WRNN_ERR_TIMEOUT, "device-side bounded spin gave up (code %u)", errw);
     return WRNN_OK;
 }

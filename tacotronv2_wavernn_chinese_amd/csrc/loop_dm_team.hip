@@ -122,6 +122,16 @@ __global__ void __launch_bounds__(DMT_THREADS, 2) dm_team_kernel(WrnnDmTeamArgs 
                 if (slot1) break;
             }
         }
+        // co-residency checked, not assumed (see loop_team2.hip): the 32 workgroups of the team's XCD must all have arrived
+        if (slot1 == 1u && rank < 32u) {
+            unsigned arrived = 0;
+            for (unsigned spins = 0; spins < WRNN_ARRIVE_POLLS; ++spins) {
+                arrived = __hip_atomic_load(&ta.ctl[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived >= 32u) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (arrived < 32u) { atomicCAS(ta.err, 0u, WRNN_DEVERR_BUSY); slot1 = 0; }
+        }
         misc_i[0] = slot1 ? (int)slot1 - 1 : 1 << 20;
         misc_i[1] = (int)rank;
         misc_i[2] = 0;   // bail-out flag

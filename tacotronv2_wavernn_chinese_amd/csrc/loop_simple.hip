@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(SIMPLE_THREADS) loop_simple_kernel(WrnnLoopArg
     if (tid == 0) *s_xfeed = a.x_init ? a.x_init[row] : 0.0f;
     __syncthreads();
 
-    for (int64_t t = 0; t < a.steps; ++t) {
+    for (int64_t t = 0; t < rw.steps; ++t) {   // the row's own length (ragged batch) or the call's
         // ---- conditioning row for this step: m_t, a_t  (:203-206) ----------
         const int64_t pos = rw.start + t;
         const bool live = pos < a.total_len;  // fold padding 'after' is zeros (:327-330)

@@ -220,7 +220,7 @@ constexpr unsigned G_X3 = 0, G_F1 = 1024, G_F2 = 2048, G_PR = 3072, G_GH = 4096;
         }                                                                   \
     } while (0)
 
-template <int MODE, bool PROF>
+template <int MODE, bool PROF, bool RAGGED>
 __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
@@ -233,6 +233,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool isC = wave < 4;
     const int wl = wave & 3;
+    // the two waves of a SIMD compete for issue slots: the critical waves go first, the shadow waves fill the gaps (measured
+    // A/B on one box, profiles/r03_team2_experiments.txt: 3.342 -> 3.305 us per step)
+    if (isC) __builtin_amdgcn_s_setprio(3);
     const int r4 = lane >> 4, q = lane & 15;
     const WrnnDims d = a.d;
     const int NC = d.NC, HOP = d.HOP, T = a.T;
@@ -246,16 +249,21 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         const unsigned x = xcc_id2();
         misc_i[M_DEAD] = 0;
         const unsigned rank = atomicAdd(&a.ctl[x], 1u);
-        unsigned slot1 = 0;
+        unsigned slot1 = 0, arrived = 0;
         if (rank == 0) {
             slot1 = atomicAdd(&a.ctl[8], 1u) + 1u;
             __hip_atomic_store(&a.ctl[16 + x], slot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            for (unsigned spins = 0; spins < 4000000u; ++spins) {
-                slot1 = __hip_atomic_load(&a.ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (slot1) break;
-            }
         }
+        // Co-residency, checked instead of assumed: the 32 workgroups of this XCD spin on each other for the whole launch, so
+        // all of them must be running NOW.  One bounded wait (~0.1 s) for the team slot AND the arrival counter; if the counter
+        // does not fill -- the GPU is shared with another process's kernel -- report WRNN_ERR_BUSY and leave instead of timing
+        // out inside the loop.
+        for (unsigned spins = 0; spins < WRNN_ARRIVE_POLLS; ++spins) {
+            slot1 = __hip_atomic_load(&a.ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived = __hip_atomic_load(&a.ctl[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (slot1 && arrived >= T2_WGS) break;
+        }
+        if (arrived < T2_WGS) { slot1 = 0; if (rank < T2_WGS) atomicCAS(a.err, 0u, WRNN_DEVERR_BUSY); }
         misc_i[0] = slot1 ? (int)slot1 - 1 : 1 << 20;   // no slot seen: treated as "not in a team" below
         misc_i[1] = (int)rank;
     }
@@ -315,9 +323,22 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
     u64 prof_acc[17] = {0};
     u64 prof_last = 0;
 
-    for (int row = team; row < a.n_rows; row += a.n_teams) {
+    // Uniform batch: team t runs rows t, t + n_teams, ... for steps [seg0, seg0 + seg_len).  RAGGED (opts.frames_dev): team t runs
+    // a.sched[t], a.sched[t + n_teams], ... (-1 = nothing; the longest-first rows dealt in snake order by rows_kernel, prologue.hip)
+    // and every row stops at its own length.  A separate instantiation: the uniform kernel is at its register limit, one more
+    // live scalar costs ~4 % of the step (measured: SGPR spills through v_writelane / v_readlane on the serial chain).
+    for (int it = team; it < (RAGGED ? a.n_slots : a.n_rows); it += a.n_teams) {
+        int row = it;
+        if constexpr (RAGGED) {
+            row = a.sched[it];
+            if (row < 0) continue;
+        }
         const WrnnRow rw = a.rows[row];
-        const int64_t seg_end = a.seg0 + a.seg_len;   // this launch runs steps [seg0, seg_end) of every row
+        int64_t seg_end = a.seg0 + a.seg_len;   // this launch runs steps [seg0, seg_end) of the row
+        if constexpr (RAGGED) {
+            if (a.seg0 >= rw.steps) continue;   // a shorter row: finished in an earlier segment
+            if (seg_end > rw.steps) seg_end = rw.steps;
+        }
         const bool resume = a.seg0 > 0;
         float *st = a.state + (size_t)row * WRNN_TEAM_STATE_FLOATS;   // [h1 | h2 | gh1 | gh2 | x]
         const float4 *CONDg = (const float4 *)a.tabCOND + ((size_t)row * a.seg_len - (size_t)a.seg0) * 512;
@@ -663,7 +684,7 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             }
         }
         __syncthreads();
-        if (seg_end < a.steps) {   // hand the recurrent state to the next segment's launch
+        if (seg_end < (RAGGED ? (int64_t)a.rows[row].steps : a.steps)) {   // hand the recurrent state to the next segment's launch
             if (g == 0) {
                 st[tid] = h1_j;
                 st[512 + tid] = xb[XB_H2 * XB_VEC + pj];
@@ -678,30 +699,41 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
     }
 }
 
-hipError_t wrnn_team2_occupancy(int *blocks_per_cu, size_t *lds_bytes) {
+// which instantiation (mode, prof, ragged) launches: the instrumented build exists for RAW uniform batches only
+static const void *team2_fn(int mode, bool prof, bool ragged) {
+    if (mode == WRNN_MODE_RAW) {
+        if (ragged) return (const void *)loop_team2_kernel<WRNN_MODE_RAW, false, true>;
+        return prof ? (const void *)loop_team2_kernel<WRNN_MODE_RAW, true, false> : (const void *)loop_team2_kernel<WRNN_MODE_RAW, false, false>;
+    }
+    return ragged ? (const void *)loop_team2_kernel<WRNN_MODE_MOL, false, true> : (const void *)loop_team2_kernel<WRNN_MODE_MOL, false, false>;
+}
+
+hipError_t wrnn_team2_occupancy(int mode, bool prof, int *blocks_per_cu, size_t *lds_bytes) {
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
     *lds_bytes = lds;
-    const void *fn = (const void *)loop_team2_kernel<WRNN_MODE_RAW, false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, T2_THREADS, lds);
+    int worst = 1 << 30;
+    for (int ragged = 0; ragged < 2; ++ragged) {
+        const void *fn = team2_fn(mode, prof, ragged != 0);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int blocks = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, T2_THREADS, lds);
+        if (e != hipSuccess) return e;
+        if (blocks < worst) worst = blocks;
+    }
+    *blocks_per_cu = worst;
+    return hipSuccess;
 }
 
 hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s) {
     (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
+    const bool ragged = a.ragged != 0, prof = a.prof != nullptr && a.d.mode == WRNN_MODE_RAW && !ragged;
     // the attribute is per device (function objects are per-device in the runtime): set it on every launch, it is a
     // host-side table write
-    const void *fn = a.prof && a.d.mode == WRNN_MODE_RAW ? (const void *)loop_team2_kernel<WRNN_MODE_RAW, true>
-                     : a.d.mode == WRNN_MODE_RAW         ? (const void *)loop_team2_kernel<WRNN_MODE_RAW, false>
-                                                         : (const void *)loop_team2_kernel<WRNN_MODE_MOL, false>;
+    const void *fn = team2_fn(a.d.mode, prof, ragged);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (a.prof && a.d.mode == WRNN_MODE_RAW)
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, true>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
-    else if (a.d.mode == WRNN_MODE_RAW)
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_RAW, false>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
-    else
-        hipLaunchKernelGGL((loop_team2_kernel<WRNN_MODE_MOL, false>), dim3(a.n_teams * 32), dim3(T2_THREADS), lds, s, a);
-    return hipGetLastError();
+    void *args[] = {(void *)&a};
+    return hipLaunchKernel(fn, dim3(a.n_teams * 32), dim3(T2_THREADS), args, lds, s);
 }

@@ -124,6 +124,9 @@ hipError_t wrnn_launch_resnet(const wrnn_handle *h, const float *mels, int B, in
     dim3 grid((T + RESNET_FT - 1) / RESNET_FT, B);
     size_t lds = ((size_t)(RESNET_FT + d.KS - 1) * d.F + 2 * (size_t)RESNET_FT * d.C) * sizeof(float);
     const int nthr = (((d.C > d.R ? d.C : d.R) + 63) / 64) * 64;
+    // wrnn_create admits any dims whose window fits a CU's 160 KB: above the default 64 KB the launch needs the attribute
+    hipError_t e = hipFuncSetAttribute((const void *)resnet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(resnet_kernel, grid, dim3(nthr), lds, s, h->wdev, h->off, d, mels, T, mel_T, mel_off, aux_frames);
     return hipGetLastError();
 }
@@ -218,6 +221,9 @@ hipError_t wrnn_launch_frame_linear(int mode, const float *src, size_t src_bstri
     (void)hipGetLastError();  // the runtime is shared with PyTorch: drop any stale sticky error of this thread
     dim3 grid((frames + 7) / 8, (N + 127) / 128, B);
     const size_t lds = (size_t)8 * K * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(mode == 0 ? (const void *)frame_linear_kernel<0> : (const void *)frame_linear_kernel<1>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     if (mode == 0)
         hipLaunchKernelGGL(frame_linear_kernel<0>, grid, dim3(128), lds, s, src, src_bstride, ld, valid, Wt, ldw, bias, out,
                            out_bstride, frames, K, N, T, P);
@@ -344,18 +350,58 @@ hipError_t wrnn_launch_pack_records32(const float *CM, const float *CA, const fl
 // The loop's row table, built on the device (no host staging buffer, no synchronisation in wrnn_generate):
 // unbatched: row r = utterance r from position 0; batched (fold_with_overlap :332-338): row r = utterance 0 from
 // position r * (target + overlap).
-__global__ void rows_kernel(WrnnRow *rows, int n_rows, int batched, long stride) {
+__global__ void rows_kernel(WrnnRow *rows, int32_t *order, int32_t *sched, int n_rows, int n_teams, int batched, long stride, long steps,
+                            const int32_t *frames, int T, int hop) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
+    const int n_slots = (n_rows + n_teams - 1) / n_teams * n_teams;
+    if (r >= n_rows) {
+        // empty slots of the last (partial) pass: slot p * n_teams + team with no row behind it
+        if (r < n_slots) {
+            const int pass = r / n_teams, pos = r - pass * n_teams;
+            const int src = pass * n_teams + ((frames && (pass & 1)) ? n_teams - 1 - pos : pos);
+            if (src >= n_rows) sched[r] = -1;
+        }
+        return;
+    }
+    auto len = [&](int i) -> long {
+        if (!frames) return steps;
+        int f = frames[i];
+        f = f < 1 ? 1 : (f > T ? T : f);
+        return (long)f * hop;
+    };
     WrnnRow w;
     w.utt = batched ? 0 : r;
-    w.pad_ = 0;
+    const long mine = len(r);
+    w.steps = (int32_t)mine;
     w.start = batched ? (int64_t)r * stride : 0;
     rows[r] = w;
+    // schedule order: longest first, ties by index (a rank scan: n_rows is at most a few thousand utterances)
+    int rank = r;
+    if (frames) {
+        rank = 0;
+        for (int j = 0; j < n_rows; ++j) {
+            const long lj = len(j);
+            rank += (lj > mine || (lj == mine && j < r)) ? 1 : 0;
+        }
+    }
+    order[rank] = r;
+    // TEAM2: rank k goes to team k % n_teams on even passes, to the mirrored team on odd passes of a ragged batch
+    const int pass = rank / n_teams, pos = rank - pass * n_teams;
+    sched[pass * n_teams + ((frames && (pass & 1)) ? n_teams - 1 - pos : pos)] = r;
+    // a thread past n_rows handles its own empty slot above; slots < n_rows that no rank maps to exist only in the last pass
+    if (r < n_slots) {
+        const int p2 = r / n_teams, q2 = r - p2 * n_teams;
+        const int src = p2 * n_teams + ((frames && (p2 & 1)) ? n_teams - 1 - q2 : q2);
+        if (src >= n_rows) sched[r] = -1;
+    }
 }
 
-hipError_t wrnn_launch_rows(WrnnRow *rows, int n_rows, int batched, long stride, hipStream_t s) {
+hipError_t wrnn_launch_rows(WrnnRow *rows, int32_t *order, int32_t *sched, int n_rows, int n_teams, int batched, long stride, long steps,
+                            const int32_t *frames, int T, int hop, hipStream_t s) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, rows, n_rows, batched, stride);
+    if (n_teams < 1) n_teams = 1;
+    const int n_slots = (n_rows + n_teams - 1) / n_teams * n_teams;
+    hipLaunchKernelGGL(rows_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, rows, order, sched, n_rows, n_teams, batched, stride, steps,
+                       frames, T, hop);
     return hipGetLastError();
 }

@@ -1,0 +1,586 @@
+// wrnn_train_step: WaveRNN.forward (fatchord_version.py:131-167) + the training script's loss (wavernn_train.py:82,112-121,
+// wavernn/utils/distribution.py:16-84) + the BACKWARD pass through the loop layers, i.e. what `loss.backward()` computes for
+// I, rnn1, rnn2, fc1, fc2, fc3 and for the conditioning tensors (mels_up, aux) the upsample network produced.
+//
+// Training is teacher-forced: every input x_t is known up front, so the layers are NOT evaluated sample by sample like
+// generate() -- everything except the two recurrences is one batched fp32 GEMM over all B*L (batch, step) pairs:
+//   XI  = [x | mels | a1] . W_I^T + b_I              GI1 = XI . W_ih1^T + b_ih1
+//   H1  = GRU1 recurrence over t (h_t = cell(GI1[t], h_{t-1}))            X2 = XI + H1
+//   GI2 = [X2 | a2] . W_ih2^T + b_ih2                H2 = GRU2 recurrence  X3 = X2 + H2
+//   F1  = relu([X3 | a3] . W_fc1^T + b1)   F2 = relu([F1 | a4] . W_fc2^T + b2)   Y = F2 . W_fc3^T + b3
+// and the same in reverse (dW = dOut^T . In, dIn = dOut . W) with BPTT through the two recurrences.  The concatenations are
+// never materialised: a layer over [x | a] is two GEMMs on column blocks of the weight.
+//
+// Kernels here:
+//   sgemm_kernel<TA,TB>   C = (beta) C + A.B (+ bias) (relu): 128x128x16 block tile, 4 waves x (2x2) v_mfma_f32_32x32x2f32 tiles,
+//                         operands staged through LDS k-major (conflict-free operand reads), register double-buffered global loads.
+//                         fp32 in, fp32 accumulate: the bound is the fp32 matrix peak (157 TFLOP/s).
+//   gru_fwd_step_kernel   one launch per time step: gh = h_{t-1} . W_hh^T for 4 hidden units x 32 batch rows per workgroup
+//                         (weights + h_{t-1} through LDS), gates, h_t; saves r, z, n, gh_n and h for the backward pass.
+//   gru_bwd_step_kernel   one launch per time step, t = L-1 .. 0: carry = dGH_{t+1} . W_hh (+ dH_{t+1} z), gate derivatives of step t.
+//   ce_grad / mol_grad    d(mean loss) / d(fc3 outputs); col_sum (bias gradients); small elementwise helpers.
+// The step launches are launch-bound (a few us of work each): they are captured ONCE per (B, L) into hipGraphs and replayed.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "wrnn_internal.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define GT_M 128
+#define GT_N 128
+#define GT_K 16
+#define GT_LD (GT_M + 4)
+
+// A(m,k) = TA ? A[k*lda + m] : A[m*lda + k];  B(k,n) = TB ? B[n*ldb + k] : B[k*ldb + n]
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) sgemm_kernel(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                                    float *__restrict__ C, long ldc, int M, int N, int K, int beta,
+                                                    const float *__restrict__ bias, int relu) {
+    __shared__ float As[GT_K][GT_LD];
+    __shared__ float Bs[GT_K][GT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.y * GT_M, n0 = (long)blockIdx.x * GT_N;
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (TA) {   // m contiguous
+                const int m = tid & 127, k = (tid >> 7) + 2 * i;
+                const long gm = m0 + m;
+                const int gk = k0 + k;
+                ra[i] = (gm < M && gk < K) ? A[(long)gk * lda + gm] : 0.0f;
+            } else {    // k contiguous
+                const int k = tid & 15, m = (tid >> 4) + 16 * i;
+                const long gm = m0 + m;
+                const int gk = k0 + k;
+                ra[i] = (gm < M && gk < K) ? A[gm * lda + gk] : 0.0f;
+            }
+            if (TB) {   // k contiguous
+                const int k = tid & 15, n = (tid >> 4) + 16 * i;
+                const long gn = n0 + n;
+                const int gk = k0 + k;
+                rb[i] = (gn < N && gk < K) ? B[gn * ldb + gk] : 0.0f;
+            } else {    // n contiguous
+                const int n = tid & 127, k = (tid >> 7) + 2 * i;
+                const long gn = n0 + n;
+                const int gk = k0 + k;
+                rb[i] = (gn < N && gk < K) ? B[(long)gk * ldb + gn] : 0.0f;
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (TA) As[(tid >> 7) + 2 * i][tid & 127] = ra[i];
+            else As[tid & 15][(tid >> 4) + 16 * i] = ra[i];
+            if (TB) Bs[tid & 15][(tid >> 4) + 16 * i] = rb[i];
+            else Bs[(tid >> 7) + 2 * i][tid & 127] = rb[i];
+        }
+    };
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.0f;
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += GT_K) {
+        __syncthreads();
+        stash();
+        __syncthreads();
+        if (k0 + GT_K < K) fetch(k0 + GT_K);
+        const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < GT_K; kk += 2) {
+            const float a0 = As[kk + kh][wm * 64 + r], a1 = As[kk + kh][wm * 64 + 32 + r];
+            const float b0 = Bs[kk + kh][wn * 64 + r], b1 = Bs[kk + kh][wn * 64 + 32 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // D[i][j] of a 32x32 tile: j = lane % 32, i = 8 * (v / 4) + 4 * (lane / 32) + v % 4
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const long gn = n0 + wn * 64 + tj * 32 + (lane & 31);
+            if (gn >= N) continue;
+            const float bv = bias ? bias[gn] : 0.0f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const long gm = m0 + wm * 64 + ti * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+                if (gm >= M) continue;
+                float o = acc[ti][tj][v] + bv;
+                if (beta) o += C[gm * ldc + gn];
+                if (relu) o = fmaxf(o, 0.0f);
+                C[gm * ldc + gn] = o;
+            }
+        }
+}
+
+hipError_t gemm(hipStream_t s, bool ta, bool tb, const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K,
+                int beta = 0, const float *bias = nullptr, int relu = 0) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    dim3 grid((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M);
+    if (ta && tb) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
+    else if (ta) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
+    else if (tb) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
+    else hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
+    return hipGetLastError();
+}
+
+// ---- small elementwise / reduction kernels --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ o, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+// g *= (act > 0)   (backward of relu, :218,:221)
+__global__ void __launch_bounds__(256) relu_bwd_kernel(float *__restrict__ g, const float *__restrict__ act, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && !(act[i] > 0.0f)) g[i] = 0.0f;
+}
+// dst[r][c] = src[c][r]   (rows x cols of dst)
+__global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (bx + tx < rows && by + i < cols) t[i][tx] = src[(size_t)(by + i) * rows + bx + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (bx + i < rows && by + tx < cols) dst[(size_t)(bx + i) * cols + by + tx] = t[tx][i];
+}
+// out[n] = sum_m A[m * lda + n]: one workgroup per 64 columns, fixed summation order (4 row lanes, then 4 partials)
+__global__ void __launch_bounds__(256) col_sum_kernel(const float *__restrict__ A, long lda, long M, int N, float *__restrict__ out) {
+    __shared__ double part[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    double acc = 0.0;
+    if (n < N)
+        for (long m = rl; m < M; m += 4) acc += (double)A[m * lda + n];
+    part[rl][c] = acc;
+    __syncthreads();
+    if (rl == 0 && n < N) out[n] = (float)((part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- GRU recurrence, forward: one launch per time step ---------------------------------------------------------------------
+// nn.GRU, one layer (gate order r, z, n; get_gru_cell :273-279):  gi = GI[b, t] (input part incl. b_ih, precomputed),
+// gh = W_hh h_{t-1} + b_hh;  r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h = (1 - z) n + z h_{t-1}.
+// grid (H / 4, ceil(B / 32)), block 256: wave u = hidden unit j0 + u, lane = (K half kh, batch row b).
+#define GR_UW 4
+#define GR_HLD(H) ((H) + 4)
+__global__ void __launch_bounds__(256) gru_fwd_step_kernel(const float *__restrict__ GI, const float *__restrict__ Whh, const float *__restrict__ bhh,
+                                                           float *__restrict__ Hs /* (B, L, H) h_t */, float *__restrict__ HP /* (B, L, H) h_{t-1} */,
+                                                           float *__restrict__ Rs, float *__restrict__ Zs, float *__restrict__ Ns,
+                                                           float *__restrict__ GHN, int B, long L, int H, long t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *hs = sm;                                    // [32][H + 4]
+    float *ws = sm + 32 * GR_HLD(H);                   // [3 gates][4 units][H]
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * GR_UW, b0 = blockIdx.y * 32;
+    const int hld = GR_HLD(H);
+    for (int i = tid; i < 32 * H; i += 256) {
+        const int b = i / H, k = i - b * H;
+        hs[b * hld + k] = (b0 + b < B) ? HP[((size_t)(b0 + b) * L + t) * H + k] : 0.0f;
+    }
+    for (int i = tid; i < 3 * GR_UW * H; i += 256) {
+        const int row = i / H, k = i - row * H;        // row = g * 4 + u
+        ws[i] = Whh[((size_t)(row >> 2) * H + j0 + (row & 3)) * H + k];
+    }
+    __syncthreads();
+    const int u = tid >> 6, kh = (tid >> 5) & 1, b = tid & 31;
+    const int kq = H / 2;
+    const float4 *hp = (const float4 *)(hs + b * hld + kh * kq);
+    const float4 *wr = (const float4 *)(ws + (0 * GR_UW + u) * H + kh * kq);
+    const float4 *wz = (const float4 *)(ws + (1 * GR_UW + u) * H + kh * kq);
+    const float4 *wn = (const float4 *)(ws + (2 * GR_UW + u) * H + kh * kq);
+    float ar = 0.f, az = 0.f, an = 0.f;
+    for (int k = 0; k < kq / 4; ++k) {
+        const float4 hv = hp[k], a = wr[k], c = wz[k], d = wn[k];
+        ar = fmaf(a.w, hv.w, fmaf(a.z, hv.z, fmaf(a.y, hv.y, fmaf(a.x, hv.x, ar))));
+        az = fmaf(c.w, hv.w, fmaf(c.z, hv.z, fmaf(c.y, hv.y, fmaf(c.x, hv.x, az))));
+        an = fmaf(d.w, hv.w, fmaf(d.z, hv.z, fmaf(d.y, hv.y, fmaf(d.x, hv.x, an))));
+    }
+    ar += __shfl_xor(ar, 32, 64); az += __shfl_xor(az, 32, 64); an += __shfl_xor(an, 32, 64);
+    if (kh == 0 && b0 + b < B) {
+        const int j = j0 + u;
+        const size_t row = (size_t)(b0 + b) * L + t;
+        const float *gi = GI + row * 3 * H;
+        const float ghr = ar + bhh[j], ghz = az + bhh[H + j], ghn = an + bhh[2 * H + j];
+        const float r = sigm(gi[j] + ghr), z = sigm(gi[H + j] + ghz);
+        const float n = tanhf(gi[2 * H + j] + r * ghn);
+        const float hprev = hs[b * hld + j];
+        const float h = (1.0f - z) * n + z * hprev;
+        Hs[row * H + j] = h;
+        if (t + 1 < L) HP[(row + 1) * H + j] = h;
+        Rs[row * H + j] = r; Zs[row * H + j] = z; Ns[row * H + j] = n; GHN[row * H + j] = ghn;
+    }
+}
+
+// ---- GRU recurrence, backward: one launch per time step, t = L-1 .. 0 ------------------------------------------------------
+// dH_t = dHext[b, t] (from the layers above: x_out = x_in + h) + carry_t,   carry_t = dH_{t+1} z_{t+1} + dGH_{t+1} . W_hh
+// dn = dH (1 - z), dz = dH (h_{t-1} - n), dpn = dn (1 - n^2), dr = dpn gh_n, dpr = dr r (1 - r), dpz = dz z (1 - z)
+// dGI_t = [dpr, dpz, dpn]   dGH_t = [dpr, dpz, dpn r]   CD_t = dH z      (dGI / dGH feed the batched weight / input GEMMs)
+// WhhT = W_hh transposed, [H][3H]: the workgroup's 4 units are 4 contiguous rows.  Same grid / thread map as the forward step.
+#define GB_KC 768
+__global__ void __launch_bounds__(256) gru_bwd_step_kernel(const float *__restrict__ dHext, const float *__restrict__ WhhT,
+                                                           const float *__restrict__ HP, const float *__restrict__ Rs, const float *__restrict__ Zs,
+                                                           const float *__restrict__ Ns, const float *__restrict__ GHN, float *__restrict__ dGI,
+                                                           float *__restrict__ dGH, float *__restrict__ CD /* (B, H) */, int B, long L, int H,
+                                                           long t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *gs = sm;                                    // [32][GB_KC + 4] chunk of dGH_{t+1}
+    float *ws = sm + 32 * (GB_KC + 4);                 // [4 units][3H]
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * GR_UW, b0 = blockIdx.y * 32;
+    const int u = tid >> 6, kh = (tid >> 5) & 1, b = tid & 31;
+    const int G = 3 * H;
+    float carry = 0.0f;
+    if (t + 1 < L) {
+        for (int i = tid; i < GR_UW * G; i += 256) ws[i] = WhhT[(size_t)j0 * G + i];
+        float acc = 0.0f;
+        for (int c0 = 0; c0 < G; c0 += GB_KC) {
+            const int cw = G - c0 < GB_KC ? G - c0 : GB_KC;
+            __syncthreads();
+            for (int i = tid; i < 32 * cw; i += 256) {
+                const int bb = i / cw, k = i - bb * cw;
+                gs[bb * (GB_KC + 4) + k] = (b0 + bb < B) ? dGH[((size_t)(b0 + bb) * L + t + 1) * G + c0 + k] : 0.0f;
+            }
+            __syncthreads();
+            const int half = cw / 2;                   // cw is a multiple of 8 for the supported dims (3H, H % 8 == 0)
+            const float4 *gp = (const float4 *)(gs + b * (GB_KC + 4) + kh * half);
+            const float4 *wp = (const float4 *)(ws + u * G + c0 + kh * half);
+            for (int k = 0; k < half / 4; ++k) {
+                const float4 gv = gp[k], wv = wp[k];
+                acc = fmaf(wv.w, gv.w, fmaf(wv.z, gv.z, fmaf(wv.y, gv.y, fmaf(wv.x, gv.x, acc))));
+            }
+        }
+        acc += __shfl_xor(acc, 32, 64);
+        carry = acc;
+    }
+    if (kh == 0 && b0 + b < B) {
+        const int j = j0 + u;
+        const size_t row = (size_t)(b0 + b) * L + t;
+        if (t + 1 < L) carry += CD[(size_t)(b0 + b) * H + j];
+        const float dH = dHext[row * H + j] + carry;
+        const float r = Rs[row * H + j], z = Zs[row * H + j], n = Ns[row * H + j], ghn = GHN[row * H + j];
+        const float hprev = HP[row * H + j];
+        const float dn = dH * (1.0f - z), dz = dH * (hprev - n);
+        const float dpn = dn * (1.0f - n * n);
+        const float dpr = (dpn * ghn) * r * (1.0f - r), dpz = dz * z * (1.0f - z);
+        float *gi = dGI + row * G, *gh = dGH + row * G;
+        gi[j] = dpr; gi[H + j] = dpz; gi[2 * H + j] = dpn;
+        gh[j] = dpr; gh[H + j] = dpz; gh[2 * H + j] = dpn * r;
+        CD[(size_t)(b0 + b) * H + j] = dH * z;
+    }
+}
+
+// ---- loss gradients: d(mean loss) / d(fc3 output) --------------------------------------------------------------------------
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// F.cross_entropy (mean): dY = (softmax(row) - onehot(y)) / n_rows.  One wave per row.
+__global__ void __launch_bounds__(256) ce_grad_kernel(const float *__restrict__ logits, const int32_t *__restrict__ y, int NC, long n_rows,
+                                                      float inv_n, float *__restrict__ dY) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float *p = logits + (size_t)row * NC;
+    float m = -INFINITY;
+    for (int c = lane; c < NC; c += 64) m = fmaxf(m, p[c]);
+    m = wmax(m);
+    float s = 0.0f;
+    for (int c = lane; c < NC; c += 64) s += expf(p[c] - m);
+    s = wsum(s);
+    const int tgt = y[row];
+    float *d = dY + (size_t)row * NC;
+    for (int c = lane; c < NC; c += 64) d[c] = (expf(p[c] - m) / s - (c == tgt ? 1.0f : 0.0f)) * inv_n;
+}
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// discretized_mix_logistic_loss (distribution.py:16-84; num_classes 65536, log_scale_min log(1e-14), reduce=True -> mean):
+// loss_row = -logsumexp_k(D_k + log_softmax(logit)_k);  w = softmax_k of that sum;  d/dlogit_j = softmax(logit)_j - w_j;
+// D_k is the arm the reference's masks select (its blends multiply the other arm by 0):
+//   y < -0.999: log s(plus)            dD/dplus = s(-plus)
+//   y >  0.999: -softplus(min)         dD/dmin  = -s(min)
+//   cdf_delta > 1e-5: log(cdf_delta)   dD/dplus = s'(plus) / cdf_delta, dD/dmin = -s'(min) / cdf_delta
+//   else: mid - ls - 2 softplus(mid) - log((nc-1)/2)   dD/dmid = 1 - 2 s(mid), dD/dls (direct) = -1
+// with plus/min/mid = exp(-ls) (y - mean +- 1/(nc-1) | 0): d/dmean = -exp(-ls), d/dls = -(value); ls = max(raw, ls_min) passes
+// the gradient to raw where raw >= ls_min (torch.clamp).  One thread per row.
+__global__ void __launch_bounds__(256) mol_grad_kernel(const float *__restrict__ y_hat, const float *__restrict__ yv, int nr, long n_rows,
+                                                       float num_classes, float ls_min, float inv_n, float *__restrict__ dY) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const float *p = y_hat + (size_t)row * 3 * nr;
+    float *d = dY + (size_t)row * 3 * nr;
+    const float y = yv[row];
+    float lm = -INFINITY;
+    for (int k = 0; k < nr; ++k) lm = fmaxf(lm, p[k]);
+    float lsum = 0.0f;
+    for (int k = 0; k < nr; ++k) lsum += expf(p[k] - lm);
+    const float lse_logit = lm + logf(lsum);
+    const float hb = 1.0f / (num_classes - 1.0f), log_half = logf((num_classes - 1.0f) / 2.0f);
+    float lp[16], dmean[16], dls[16];
+    float mx = -INFINITY;
+    for (int k = 0; k < nr; ++k) {
+        const float mean = p[nr + k], raw = p[2 * nr + k];
+        const float ls = fmaxf(raw, ls_min);
+        const float cy = y - mean, inv = expf(-ls);
+        const float plus = inv * (cy + hb), mn = inv * (cy - hb), mid = inv * cy;
+        const float sp = sigm(plus), sn = sigm(mn);
+        const float cdf_delta = sp - sn;
+        float D, dplus = 0.f, dmin = 0.f, dmid = 0.f, ddirect = 0.f;
+        if (y < -0.999f) { D = plus - softplus_t(plus); dplus = 1.0f - sp; }
+        else if (y > 0.999f) { D = -softplus_t(mn); dmin = -sn; }
+        else if (cdf_delta > 1e-5f) { D = logf(fmaxf(cdf_delta, 1e-12f)); dplus = sp * (1.0f - sp) / cdf_delta; dmin = -sn * (1.0f - sn) / cdf_delta; }
+        else { D = mid - ls - 2.0f * softplus_t(mid) - log_half; dmid = 1.0f - 2.0f * sigm(mid); ddirect = -1.0f; }
+        dmean[k] = -inv * (dplus + dmin + dmid);
+        dls[k] = (raw >= ls_min) ? (-(dplus * plus + dmin * mn + dmid * mid) + ddirect) : 0.0f;
+        lp[k] = D + (p[k] - lse_logit);
+        mx = fmaxf(mx, lp[k]);
+    }
+    float s = 0.0f;
+    for (int k = 0; k < nr; ++k) s += expf(lp[k] - mx);
+    for (int k = 0; k < nr; ++k) {
+        const float w = expf(lp[k] - mx) / s;
+        d[k] = (expf(p[k] - lse_logit) - w) * inv_n;
+        d[nr + k] = -w * dmean[k] * inv_n;
+        d[2 * nr + k] = -w * dls[k] * inv_n;
+    }
+}
+
+}  // namespace
+
+// Workspace of one (B, L) problem and the captured step graphs (owned by the handle).
+struct WrnnTrainState {
+    float *ws = nullptr;
+    size_t ws_floats = 0;
+    int B = 0;
+    long L = 0;
+    hipGraphExec_t g_fwd[2] = {nullptr, nullptr}, g_bwd[2] = {nullptr, nullptr};   // [GRU1, GRU2]
+    const float *w_hh[2] = {nullptr, nullptr}, *b_hh[2] = {nullptr, nullptr};       // weight pointers baked into the graphs
+    hipStream_t cap = nullptr;
+};
+
+void wrnn_train_state_free(WrnnTrainState *st) {
+    if (!st) return;
+    for (int i = 0; i < 2; ++i) {
+        if (st->g_fwd[i]) (void)hipGraphExecDestroy(st->g_fwd[i]);
+        if (st->g_bwd[i]) (void)hipGraphExecDestroy(st->g_bwd[i]);
+    }
+    if (st->cap) (void)hipStreamDestroy(st->cap);
+    if (st->ws) (void)hipFree(st->ws);
+    delete st;
+}
+
+namespace {
+
+int tfail(wrnn_handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    h->err = buf;
+    return code;
+}
+#define T_TRY(expr)                                                                                       \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) return tfail(h, WRNN_ERR_HIP, "wrnn_train_step: %s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+struct Gru {   // one recurrence's buffers
+    float *GI, *H, *HP, *R, *Z, *N, *GHN, *dGI, *dGH, *CD, *WhhT;
+};
+
+// the L step launches of one recurrence as a graph (captured once per (B, L, weight pointers)), replayed on the caller's stream
+template <class F>
+hipError_t run_steps(WrnnTrainState *st, hipGraphExec_t *slot, bool rebuild, hipStream_t s, F launch_all) {
+    hipError_t e;
+    if (rebuild && *slot) { (void)hipGraphExecDestroy(*slot); *slot = nullptr; }
+    if (!*slot) {
+        if (!st->cap && (e = hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking)) != hipSuccess) return e;
+        hipGraph_t g = nullptr;
+        if ((e = hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal)) != hipSuccess) return e;
+        launch_all(st->cap);
+        if ((e = hipStreamEndCapture(st->cap, &g)) != hipSuccess) return e;
+        e = hipGraphInstantiate(slot, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return e;
+    }
+    return hipGraphLaunch(*slot, s);
+}
+
+}  // namespace
+
+extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_params *g, const float *x_dev, const float *mels_up_dev,
+                               const float *aux_dev, const void *y_dev, int32_t B, int64_t L, float *loss_out_dev, float *logits_out_dev,
+                               float *d_mels_up_dev, float *d_aux_dev, void *stream) {
+    if (!h) return WRNN_ERR_INVALID;
+    if (!w || !x_dev || !mels_up_dev || !aux_dev || B < 1 || L < 1) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: bad arguments");
+    if (g && (!y_dev || !loss_out_dev)) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: gradients need targets and a loss output");
+    const WrnnDims &d = h->d;
+    const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, NC = d.NC;
+    if (H % 8 != 0 || H > 2048 || FC < 1) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: rnn_dims must be a multiple of 8 (<= 2048)");
+    if ((size_t)(32 * GR_HLD(H) + 3 * GR_UW * H) * 4 > 160u * 1024u || (size_t)(32 * (GB_KC + 4) + GR_UW * 3 * H) * 4 > 160u * 1024u)
+        return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: rnn_dims too large for the step kernels' LDS tiles");
+    T_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)B * L;
+    const int G = 3 * H, IN_I = 1 + F + A;
+    if (!h->train) h->train = new WrnnTrainState();
+    WrnnTrainState *st = h->train;
+    // ---- workspace carve-up (floats) ----
+    const size_t nH = (size_t)M * H, nG = (size_t)M * G, nF = (size_t)M * FC, nY = (size_t)M * NC;
+    size_t need = 0;
+    auto take = [&](size_t n) { size_t at = need; need += (n + 63) & ~(size_t)63; return at; };
+    const size_t oXI = take(nH), oX2 = take(nH), oX3 = take(nH), oF1 = take(nF), oF2 = take(nF), oY = take(nY);
+    size_t oG[2][11];
+    for (int i = 0; i < 2; ++i) {
+        oG[i][0] = take(nG); oG[i][1] = take(nH); oG[i][2] = take(nH); oG[i][3] = take(nH); oG[i][4] = take(nH); oG[i][5] = take(nH);
+        oG[i][6] = take(nH); oG[i][7] = take(nG); oG[i][8] = take(nG); oG[i][9] = take((size_t)B * H); oG[i][10] = take((size_t)H * G);
+    }
+    const size_t odY = take(nY), odF2 = take(nF), odF1 = take(nF), odX3 = take(nH), odX2 = take(nH), odXI = take(nH);
+    const bool fresh = need > st->ws_floats;
+    if (fresh) {
+        if (st->ws) (void)hipFree(st->ws);
+        st->ws = nullptr; st->ws_floats = 0;
+        T_TRY(hipMalloc(&st->ws, need * sizeof(float)));
+        st->ws_floats = need;
+    }
+    float *ws = st->ws;
+    float *XI = ws + oXI, *X2 = ws + oX2, *X3 = ws + oX3, *F1 = ws + oF1, *F2 = ws + oF2, *Y = logits_out_dev ? logits_out_dev : ws + oY;
+    Gru gr[2];
+    for (int i = 0; i < 2; ++i)
+        gr[i] = Gru{ws + oG[i][0], ws + oG[i][1], ws + oG[i][2], ws + oG[i][3], ws + oG[i][4], ws + oG[i][5], ws + oG[i][6], ws + oG[i][7],
+                    ws + oG[i][8], ws + oG[i][9], ws + oG[i][10]};
+    float *dY = ws + odY, *dF2 = ws + odF2, *dF1 = ws + odF1, *dX3 = ws + odX3, *dX2 = ws + odX2, *dXI = ws + odXI;
+    const float *whh[2] = {w->rnn1_w_hh, w->rnn2_w_hh}, *bhh[2] = {w->rnn1_b_hh, w->rnn2_b_hh};
+    // the step graphs bake buffer and weight addresses: rebuild when the problem or the parameter storage changed
+    const bool rebuild = fresh || st->B != B || st->L != L || st->w_hh[0] != whh[0] || st->w_hh[1] != whh[1] || st->b_hh[0] != bhh[0] ||
+                         st->b_hh[1] != bhh[1];
+    st->B = B; st->L = L;
+    for (int i = 0; i < 2; ++i) { st->w_hh[i] = whh[i]; st->b_hh[i] = bhh[i]; }
+    (void)hipGetLastError();
+    const size_t lds_f = (size_t)(32 * GR_HLD(H) + 3 * GR_UW * H) * sizeof(float), lds_b = (size_t)(32 * (GB_KC + 4) + GR_UW * G) * sizeof(float);
+    T_TRY(hipFuncSetAttribute((const void *)gru_fwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+    T_TRY(hipFuncSetAttribute((const void *)gru_bwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    const dim3 sgrid(H / GR_UW, (B + 31) / 32);
+    const float *a1 = aux_dev, *a2 = aux_dev + A, *a3 = aux_dev + 2 * A, *a4 = aux_dev + 3 * A;   // aux channel split (:198-199)
+
+    // ================= forward (:146-167) =================
+    // x = I(cat[x, mels, a1])
+    T_TRY(gemm(s, false, true, x_dev, 1, w->I_w, IN_I, XI, H, M, H, 1, 0, w->I_b));
+    T_TRY(gemm(s, false, true, mels_up_dev, F, w->I_w + 1, IN_I, XI, H, M, H, F, 1));
+    T_TRY(gemm(s, false, true, a1, R, w->I_w + 1 + F, IN_I, XI, H, M, H, A, 1));
+    auto recur_fwd = [&](int i) -> hipError_t {
+        const Gru &q = gr[i];
+        hipError_t e = hipMemsetAsync(q.HP, 0, nH * sizeof(float), s);   // h_{-1} = 0 (:141-142); rows t > 0 are overwritten
+        if (e != hipSuccess) return e;
+        return run_steps(st, &st->g_fwd[i], rebuild, s, [&](hipStream_t cs) {
+            for (long t = 0; t < L; ++t)
+                hipLaunchKernelGGL(gru_fwd_step_kernel, sgrid, dim3(256), lds_f, cs, q.GI, whh[i], bhh[i], q.H, q.HP, q.R, q.Z, q.N, q.GHN, B, L, H, t);
+        });
+    };
+    // rnn1 (:152-153)
+    T_TRY(gemm(s, false, true, XI, H, w->rnn1_w_ih, H, gr[0].GI, G, M, G, H, 0, w->rnn1_b_ih));
+    T_TRY(recur_fwd(0));
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((nH + 255) / 256)), dim3(256), 0, s, XI, gr[0].H, X2, (long)nH);
+    // rnn2 over cat[x, a2] (:155-158)
+    T_TRY(gemm(s, false, true, X2, H, w->rnn2_w_ih, H + A, gr[1].GI, G, M, G, H, 0, w->rnn2_b_ih));
+    T_TRY(gemm(s, false, true, a2, R, w->rnn2_w_ih + H, H + A, gr[1].GI, G, M, G, A, 1));
+    T_TRY(recur_fwd(1));
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((nH + 255) / 256)), dim3(256), 0, s, X2, gr[1].H, X3, (long)nH);
+    // fc1, fc2 (relu), fc3 (:160-166)
+    T_TRY(gemm(s, false, true, X3, H, w->fc1_w, H + A, F1, FC, M, FC, H, 0, w->fc1_b));
+    T_TRY(gemm(s, false, true, a3, R, w->fc1_w + H, H + A, F1, FC, M, FC, A, 1, nullptr, 1));
+    T_TRY(gemm(s, false, true, F1, FC, w->fc2_w, FC + A, F2, FC, M, FC, FC, 0, w->fc2_b));
+    T_TRY(gemm(s, false, true, a4, R, w->fc2_w + FC, FC + A, F2, FC, M, FC, A, 1, nullptr, 1));
+    T_TRY(gemm(s, false, true, F2, FC, w->fc3_w, FC, Y, NC, M, NC, FC, 0, w->fc3_b));
+    if (y_dev && loss_out_dev)
+        if (int rc = wrnn_loss(h, Y, y_dev, M, loss_out_dev, stream)) return rc;
+    if (!g) return WRNN_OK;
+
+    // ================= backward =================
+    const float inv_n = 1.0f / (float)M;
+    if (d.mode == WRNN_MODE_RAW)
+        hipLaunchKernelGGL(ce_grad_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, Y, (const int32_t *)y_dev, NC, M, inv_n, dY);
+    else
+        hipLaunchKernelGGL(mol_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, Y, (const float *)y_dev, NC / 3, M, 65536.0f,
+                           -32.23619130191664f, inv_n, dY);
+    auto colsum = [&](const float *Am, long lda, int N, float *out) {
+        hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64), dim3(256), 0, s, Am, lda, M, N, out);
+    };
+    const unsigned eb_f = (unsigned)((nF + 255) / 256);
+    // fc3
+    T_TRY(gemm(s, true, false, dY, NC, F2, FC, g->fc3_w, FC, NC, FC, (int)M));
+    colsum(dY, NC, NC, g->fc3_b);
+    T_TRY(gemm(s, false, false, dY, NC, w->fc3_w, FC, dF2, FC, M, FC, NC));
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(eb_f), dim3(256), 0, s, dF2, F2, (long)nF);
+    // fc2 over cat[F1, a4]
+    T_TRY(gemm(s, true, false, dF2, FC, F1, FC, g->fc2_w, FC + A, FC, FC, (int)M));
+    T_TRY(gemm(s, true, false, dF2, FC, a4, R, g->fc2_w + FC, FC + A, FC, A, (int)M));
+    colsum(dF2, FC, FC, g->fc2_b);
+    T_TRY(gemm(s, false, false, dF2, FC, w->fc2_w, FC + A, dF1, FC, M, FC, FC));
+    if (d_aux_dev) T_TRY(gemm(s, false, false, dF2, FC, w->fc2_w + FC, FC + A, d_aux_dev + 3 * A, R, M, A, FC));
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(eb_f), dim3(256), 0, s, dF1, F1, (long)nF);
+    // fc1 over cat[X3, a3]
+    T_TRY(gemm(s, true, false, dF1, FC, X3, H, g->fc1_w, H + A, FC, H, (int)M));
+    T_TRY(gemm(s, true, false, dF1, FC, a3, R, g->fc1_w + H, H + A, FC, A, (int)M));
+    colsum(dF1, FC, FC, g->fc1_b);
+    T_TRY(gemm(s, false, false, dF1, FC, w->fc1_w, H + A, dX3, H, M, H, FC));
+    if (d_aux_dev) T_TRY(gemm(s, false, false, dF1, FC, w->fc1_w + H, H + A, d_aux_dev + 2 * A, R, M, A, FC));
+    auto recur_bwd = [&](int i, const float *dHext) -> hipError_t {
+        const Gru &q = gr[i];
+        hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (G + 31) / 32), dim3(256), 0, s, whh[i], q.WhhT, H, G);   // WhhT[j][k] = W_hh[k][j]
+        return run_steps(st, &st->g_bwd[i], rebuild, s, [&](hipStream_t cs) {
+            for (long t = L - 1; t >= 0; --t)
+                hipLaunchKernelGGL(gru_bwd_step_kernel, sgrid, dim3(256), lds_b, cs, dHext, q.WhhT, q.HP, q.R, q.Z, q.N, q.GHN, q.dGI, q.dGH, q.CD, B, L,
+                                   H, t);
+        });
+    };
+    // rnn2: h2 enters x3 = x2 + h2, so dH2(ext) = dX3
+    T_TRY(recur_bwd(1, dX3));
+    T_TRY(gemm(s, true, false, gr[1].dGI, G, X2, H, g->rnn2_w_ih, H + A, G, H, (int)M));
+    T_TRY(gemm(s, true, false, gr[1].dGI, G, a2, R, g->rnn2_w_ih + H, H + A, G, A, (int)M));
+    T_TRY(gemm(s, true, false, gr[1].dGH, G, gr[1].HP, H, g->rnn2_w_hh, H, G, H, (int)M));
+    colsum(gr[1].dGI, G, G, g->rnn2_b_ih);
+    colsum(gr[1].dGH, G, G, g->rnn2_b_hh);
+    T_TRY(hipMemcpyAsync(dX2, dX3, nH * sizeof(float), hipMemcpyDeviceToDevice, s));        // residual x3 = x2 + h2
+    T_TRY(gemm(s, false, false, gr[1].dGI, G, w->rnn2_w_ih, H + A, dX2, H, M, H, G, 1));
+    if (d_aux_dev) T_TRY(gemm(s, false, false, gr[1].dGI, G, w->rnn2_w_ih + H, H + A, d_aux_dev + A, R, M, A, G));
+    // rnn1
+    T_TRY(recur_bwd(0, dX2));
+    T_TRY(gemm(s, true, false, gr[0].dGI, G, XI, H, g->rnn1_w_ih, H, G, H, (int)M));
+    T_TRY(gemm(s, true, false, gr[0].dGH, G, gr[0].HP, H, g->rnn1_w_hh, H, G, H, (int)M));
+    colsum(gr[0].dGI, G, G, g->rnn1_b_ih);
+    colsum(gr[0].dGH, G, G, g->rnn1_b_hh);
+    T_TRY(hipMemcpyAsync(dXI, dX2, nH * sizeof(float), hipMemcpyDeviceToDevice, s));        // residual x2 = xI + h1
+    T_TRY(gemm(s, false, false, gr[0].dGI, G, w->rnn1_w_ih, H, dXI, H, M, H, G, 1));
+    // I over cat[x, mels, a1]
+    T_TRY(gemm(s, true, false, dXI, H, x_dev, 1, g->I_w, IN_I, H, 1, (int)M));
+    T_TRY(gemm(s, true, false, dXI, H, mels_up_dev, F, g->I_w + 1, IN_I, H, F, (int)M));
+    T_TRY(gemm(s, true, false, dXI, H, a1, R, g->I_w + 1 + F, IN_I, H, A, (int)M));
+    colsum(dXI, H, H, g->I_b);
+    if (d_mels_up_dev) T_TRY(gemm(s, false, false, dXI, H, w->I_w + 1, IN_I, d_mels_up_dev, F, M, F, H));
+    if (d_aux_dev) T_TRY(gemm(s, false, false, dXI, H, w->I_w + 1 + F, IN_I, d_aux_dev, R, M, A, H));
+    T_TRY(hipGetLastError());
+    return WRNN_OK;
+}

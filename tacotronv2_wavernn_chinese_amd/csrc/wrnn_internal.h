@@ -60,9 +60,17 @@ struct WrnnPacked {
 // One loop row = one utterance (unbatched) or one fold (fold_with_overlap :293-340).
 struct WrnnRow {
     int32_t utt;      // index into the mel batch
-    int32_t pad_;
+    int32_t steps;    // loop steps of this row: the call's `steps`, or frames[utt] * hop in a ragged batch (opts.frames_dev)
     int64_t start;    // first upsampled position of this row
 };
+// Device error word codes (first come, first kept): 3 = a team kernel's workgroups did not all become resident (WRNN_ERR_BUSY),
+// everything else = a bounded exchange spin gave up (WRNN_ERR_TIMEOUT)
+#define WRNN_DEVERR_BUSY 3u
+// polls a workgroup waits at the start of a team kernel for the other 31 of its XCD (~1.5 ms; a resident launch needs ~10 us)
+#define WRNN_ARRIVE_POLLS 200000u
+
+struct WrnnTrainState;   // train.hip: workspace + captured step graphs of wrnn_train_step
+void wrnn_train_state_free(WrnnTrainState *st);
 
 struct wrnn_handle {
     wrnn_config cfg;
@@ -75,6 +83,8 @@ struct wrnn_handle {
     float *aux_frames = nullptr;  // (B, T, R)
     size_t aux_cap = 0;
     WrnnRow *rows_dev = nullptr;
+    int32_t *order_dev = nullptr; // [rows] rows by length, longest first, in a ragged batch; identity otherwise (BATCH kernel)
+    int32_t *sched_dev = nullptr; // [rows rounded up to n_teams] per-team row lists of the TEAM2 kernel (see WrnnTeamArgs)
     size_t rows_cap = 0;
     unsigned *err_dev = nullptr;  // device error word (bounded spins)
     // team kernel state
@@ -94,10 +104,12 @@ struct wrnn_handle {
     unsigned long long *mail = nullptr;
     unsigned *ctl = nullptr;
     int n_teams = 8;              // XCDs (32-CU teams) of this device
-    unsigned long long *prof = nullptr;   // set when WRNN_TEAM_PROF=1 in the environment
+    unsigned long long *prof = nullptr;   // phase-cycle counters, allocated by wrnn_phase_profile(h, 1)
+    bool prof_on = false;
     double prof_div = 0;
     double *loss_partial = nullptr;   // per-block partial sums of wrnn_loss
     size_t loss_cap = 0;
+    WrnnTrainState *train = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
     wrnn_timing last{};
@@ -116,7 +128,7 @@ struct WrnnLoopArgs {
     int32_t n_rows;
     int32_t T;                // mel frames per utterance
     int64_t total_len;        // T * HOP
-    int64_t steps;            // loop length per row
+    int64_t steps;            // loop length per row (the longest row's in a ragged batch; row r runs rows[r].steps)
     int32_t noise_mode;
     uint64_t seed;
     const float *noise1;      // RAW (L, rows, NC) | MOL (L, rows, 10)
@@ -154,6 +166,9 @@ struct WrnnTeamArgs {
     const float *tabC3;       // (B, T+1, FC)   fc1.W[:,H:] . a3[i] + b1
     const float *tabC4;       // (B, T+1, FC)   fc2.W[:,FC:] . a4[i] + b2
     const WrnnRow *rows;
+    const int32_t *sched;     // [n_slots] team t runs rows sched[t], sched[t + n_teams], ... (-1 = none): identity for a uniform batch,
+    int32_t n_slots;          // longest-first rows dealt in snake order (0..n-1, n-1..0, ...) for a ragged one; n_slots = n_rows rounded
+    int32_t ragged;           // up to a multiple of n_teams.  ragged != 0: use sched and the rows' own steps (opts.frames_dev)
     int32_t n_rows;
     int32_t n_teams;          // teams = XCDs in use; the launch grid is n_teams * 32 workgroups
     int32_t T;
@@ -196,10 +211,13 @@ struct WrnnBatchArgs {
     const float *u1;          // [3H]  W_ih1 . W_I[:,0]
     const float *tabREC32;    // (B, T+1, H, 32): the 24 phase-A record floats (pack_records_kernel) | c2 r,z,n | c3 | c4 | pad
     const WrnnRow *rows;
+    const int32_t *order;     // schedule slot -> row (longest first in a ragged batch, identity otherwise)
+    int32_t snake;            // != 0: batches are dealt to the teams in snake order (ragged batch), else round-robin
     int32_t n_rows;
     int32_t n_teams;
     int32_t nq;               // row quads per team: 1 (4 rows) or 2 (8 rows)
-    int32_t rpb;              // rows actually placed in one batch (<= 4 * nq): batch b = rows [b * rpb, (b + 1) * rpb)
+    int32_t rpb;              // rows actually placed in one batch (<= 4 * nq): batch b = slots [b * rpb, (b + 1) * rpb); it runs
+                              // for the steps of its first (longest) row
     int32_t T;
     int64_t total_len;
     int64_t steps;
@@ -216,7 +234,6 @@ struct WrnnBatchArgs {
     unsigned *ctl;
     unsigned *err;
     unsigned long long *prof;
-    int32_t variant;          // bit 0: ping-pong schedule of the 8-row kernel (WRNN_BATCH_PP=1; opt-in until measured)
 };
 
 // kernels / launchers (defined in the .hip files)
@@ -229,11 +246,19 @@ hipError_t wrnn_launch_materialize(const wrnn_handle *h, const float *mels, cons
 hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
 size_t wrnn_simple_lds_bytes(const WrnnDims &d);
 hipError_t wrnn_launch_loop_batch(const WrnnBatchArgs &a, hipStream_t s);
-hipError_t wrnn_batch_occupancy(int nq, int *blocks_per_cu, size_t *lds_bytes);
-hipError_t wrnn_team2_occupancy(int *blocks_per_cu, size_t *lds_bytes);
+hipError_t wrnn_batch_occupancy(int mode, int nq, bool prof, int *blocks_per_cu, size_t *lds_bytes);
+hipError_t wrnn_team2_occupancy(int mode, bool prof, int *blocks_per_cu, size_t *lds_bytes);
+// Per-device ordering of team-kernel launches inside this process (api.hip): enter() makes `s` wait for the previous team
+// kernel launched on `device` by any handle / stream and takes the device's launch lock, leave() records the new tail and
+// releases the lock.  Nothing blocks on the GPU's progress; only the launching threads are serialised.
+hipError_t wrnn_team_gate_enter(int device, hipStream_t s);
+hipError_t wrnn_team_gate_leave(int device, hipStream_t s);
 hipError_t wrnn_launch_loss(int mode, const float *y_hat, const void *y, int NC, long n_rows, double *partial, int *bad, float *out,
                             hipStream_t s);
-hipError_t wrnn_launch_rows(WrnnRow *rows, int n_rows, int batched, long stride, hipStream_t s);
+// rows[r] = {utt, steps, start}; order[] = rows sorted by steps, longest first (stable), when frames != null, else identity;
+// sched[] (n_rows rounded up to n_teams entries) = the same order dealt to n_teams teams in snake order, -1 where empty
+hipError_t wrnn_launch_rows(WrnnRow *rows, int32_t *order, int32_t *sched, int n_rows, int n_teams, int batched, long stride, long steps,
+                            const int32_t *frames, int T, int hop, hipStream_t s);
 hipError_t wrnn_launch_pack_records32(const float *CM, const float *CA, const float *VM, const float *VA, const float *C2,
                                       const float *C3, const float *C4, float *rec, int B, int T, int P, hipStream_t s);
 hipError_t wrnn_launch_loop_team2(const WrnnTeamArgs &a, hipStream_t s);

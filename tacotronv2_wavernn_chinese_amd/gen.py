@@ -46,6 +46,11 @@ def gen_from_file(model: WaveRNN, load_path, save_path, batched, target, overlap
     return save_str
 
 
+def default_weights_path(base: str = '.') -> str:
+    """``Paths(hp.voc_model_id).voc_latest_weights`` of the reference (``wavernn/utils/paths.py:8-12``)."""
+    return os.path.join(os.path.abspath(base), 'logs_wavernn', 'checkpoints', 'latest_weights.pyt')
+
+
 def build_model_from_hparams() -> WaveRNN:
     """``wavernn_gen.py:99-110``."""
     return WaveRNN(rnn_dims=hp.voc_rnn_dims, fc_dims=hp.voc_fc_dims, bits=hp.bits, pad=hp.voc_pad,
@@ -90,11 +95,17 @@ def main(argv=None):
     print('Using device:', device)
     print('\nInitialising Model...\n')
     model = build_model_from_hparams().to(device)
-    if args.voc_weights:
-        print(args.voc_weights)
-        model.load(args.voc_weights)
+    # wavernn_gen.py:112-117: `--voc_weights`, else the latest checkpoint of the training run
+    # (Paths.voc_latest_weights = <base>/logs_wavernn/checkpoints/latest_weights.pyt, wavernn/utils/paths.py:11-12; <base> is
+    # the directory the script is started from here).  The reference then dies in torch.load when that file is absent; no
+    # checkpoint ships with the repository (.MISSING_LARGE_BLOBS), so an absent default falls back to the seeded random
+    # initialisation, loudly.
+    voc_weights = args.voc_weights if args.voc_weights else default_weights_path()
+    print(voc_weights)
+    if args.voc_weights or os.path.exists(voc_weights):
+        model.load(voc_weights)
     else:
-        print('no --voc_weights given: using the randomly initialised model')
+        print(f'{voc_weights} does not exist and no --voc_weights given: using the randomly initialised model')
     if args.file:
         out_dir = './wavernn_inference_output'
         os.makedirs(out_dir, exist_ok=True)

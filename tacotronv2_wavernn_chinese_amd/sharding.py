@@ -21,19 +21,50 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def generate_sharded(generate_one: Callable[[int, np.ndarray], np.ndarray], mels: Sequence[np.ndarray],
-                     gather: bool = True) -> Optional[List[np.ndarray]]:
-    """Run ``generate_one(index, mel)`` for this rank's share of ``mels`` and gather all results on every rank.
+def balanced_shards(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Length-balanced assignment ("length-balanced bins since loop time is proportional to T"): longest-first
+    greedy bin packing (LPT) -- every clip, longest first, goes to the rank with the smallest total so far (ties: the lower
+    rank).  Deterministic, so every rank computes the same table without talking to the others.  Returns one index list per
+    rank, each in input order.  With equal lengths this is the round-robin assignment."""
+    if world < 1:
+        raise ValueError('world must be >= 1')
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world
+    bins: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], len(bins[k]), k))
+        bins[r].append(i)
+        load[r] += int(lengths[i])
+    return [sorted(b) for b in bins]
 
-    ``generate_one`` is typically ``lambda i, m: model.generate(m[None], path_i, False, target, overlap, mu_law)``.
-    Returns the wavs in input order (None on ranks != 0 when ``gather`` is False)."""
+
+def generate_sharded(generate_one: Optional[Callable[[int, np.ndarray], np.ndarray]], mels: Sequence[np.ndarray],
+                     gather: bool = True, balance: bool = False,
+                     generate_many: Optional[Callable[[List[int], List[np.ndarray]], Sequence[np.ndarray]]] = None
+                     ) -> Optional[List[np.ndarray]]:
+    """Run the vocoder on this rank's share of ``mels`` and gather all results on every rank.
+
+    ``generate_one(index, mel)`` is typically ``lambda i, m: model.generate(m[None], path_i, False, target, overlap, mu_law)``;
+    ``generate_many(indices, mels)`` (takes precedence) hands the rank's whole share to one call -- typically
+    ``lambda idx, ms: model.generate_many(ms)``, one ragged device call that keeps all XCD teams of the GPU busy.
+    ``balance``: assign clips by length (``balanced_shards`` over the frame counts ``mel.shape[-1]``) instead of round-robin.
+    Returns the wavs in input order (None when ``gather`` is False and there is more than one rank)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(), dist.get_world_size()
     else:
         rank, world = 0, 1
-    mine = shard_indices(len(mels), rank, world)
-    local = [(i, np.asarray(generate_one(i, mels[i]))) for i in mine]
+    if balance:
+        mine = balanced_shards([int(np.shape(m)[-1]) for m in mels], world)[rank]
+    else:
+        mine = shard_indices(len(mels), rank, world)
+    if generate_many is not None:
+        outs = generate_many(list(mine), [mels[i] for i in mine]) if mine else []
+        local = [(i, np.asarray(w)) for i, w in zip(mine, outs)]
+    else:
+        if generate_one is None:
+            raise ValueError('generate_sharded needs generate_one or generate_many')
+        local = [(i, np.asarray(generate_one(i, mels[i]))) for i in mine]
     if world == 1:
         out: List[Optional[np.ndarray]] = [None] * len(mels)
         for i, w in local:

@@ -130,7 +130,10 @@ class WaveRNN(nn.Module):
         and storage address of every tensor.  Catches ``load_state_dict``, optimizer steps, ``p.data = t`` (the idiom of
         the reference's ``get_gru_cell``) and ``.to()``.  Writes through ``p.data`` that keep the storage
         (``p.data.copy_()``, ``p.data.fill_()``) bump neither: call :meth:`invalidate_native` after those."""
-        return (dev,) + tuple((id(p), p._version, p.data_ptr()) for p in list(self.parameters()) + list(self.buffers()))
+        # `step` and BatchNorm's `num_batches_tracked` are never read by wrnn_load_weights: leaving them out keeps forward()
+        # (which bumps `step` in place, :139) from repacking and re-uploading every weight on every call
+        bufs = [b for n, b in self.named_buffers() if n != 'step' and not n.endswith('num_batches_tracked')]
+        return (dev,) + tuple((id(p), p._version, p.data_ptr()) for p in list(self.parameters()) + bufs)
 
     def invalidate_native(self):
         """Force the next ``generate`` to repack the weights into the native handle."""
@@ -179,12 +182,15 @@ class WaveRNN(nn.Module):
     # ---------------------------------------------------------------- generate
     def generate_raw(self, mels, batched, target, overlap, *, noise_mode=_cabi.NOISE_PHILOX, seed=0,
                      noise1=None, noise2=None, x_forced=None, want_logits=False, kernel=None, x_init=None,
-                     mels_padded=False):
+                     mels_padded=False, frames=None, batch_rows=0, team2_segment=0):
         """Device part of generate() (:183-241).  Returns dict(samples (rows, L) float32 cuda tensor,
         labels (rows, L) int32 cuda tensor, logits or None, rows, steps).
 
         noise1/noise2/x_forced: array-likes laid out like the reference consumes them (step-major):
         RAW noise1 (L, rows, n_classes) Exp(1) draws; MOL noise1 (L, rows, 10), noise2 (L, rows).
+        frames: optional (B,) valid frames per utterance of a ragged, right-zero-padded batch (``wrnn_sample_opts.frames_dev``):
+        row b runs frames[b] * hop steps, the rest of its output row is left unwritten (here: zero).
+        batch_rows / team2_segment: tuning knobs of the BATCH / TEAM2 kernels (0 = the library's choice).
         """
         nat = self.native()
         dev = torch.device('cuda', nat.device)
@@ -198,9 +204,17 @@ class WaveRNN(nn.Module):
             if F != self.feat_dims:   # the reference dies in conv_in with a channel mismatch (:43); a (T, n_mels) array lands here too
                 raise ValueError(f'expected mels shaped (B, {self.feat_dims}, T), got {tuple(mels_t.shape)}')
             rows, steps = nat.plan(B, T, batched, target, overlap)
-            samples = torch.empty((rows, steps), dtype=torch.float32, device=dev)
-            labels = torch.empty((rows, steps), dtype=torch.int32, device=dev)
+            ragged = frames is not None
+            samples = (torch.zeros if ragged else torch.empty)((rows, steps), dtype=torch.float32, device=dev)
+            labels = (torch.zeros if ragged else torch.empty)((rows, steps), dtype=torch.int32, device=dev)
             keep = []
+            fr = 0
+            if ragged:
+                fr_t = torch.as_tensor(frames).to(device=dev, dtype=torch.int32).contiguous()
+                if tuple(fr_t.shape) != (B,):
+                    raise ValueError(f'frames must have shape ({B},), got {tuple(fr_t.shape)}')
+                keep.append(fr_t)
+                fr = fr_t.data_ptr()
 
             def to_dev(a, shape):
                 if a is None:
@@ -221,10 +235,12 @@ class WaveRNN(nn.Module):
                          labels_ptr=labels.data_ptr(), samples_ptr=samples.data_ptr(), stream=stream,
                          noise_mode=noise_mode, seed=int(seed), noise1_ptr=n1, noise2_ptr=n2, x_forced_ptr=xf,
                          logits_ptr=logits.data_ptr() if logits is not None else 0,
-                         kernel=self.kernel if kernel is None else kernel, x_init_ptr=xi, mels_padded=mels_padded)
+                         kernel=self.kernel if kernel is None else kernel, x_init_ptr=xi, mels_padded=mels_padded,
+                         frames_ptr=fr, batch_rows=batch_rows, team2_segment=team2_segment)
             self.last_timing = nat.last_timing()  # synchronises; surfaces device-side errors
+            frames_dev = keep[0] if ragged else None
             del keep
-        return dict(samples=samples, labels=labels, logits=logits, rows=rows, steps=steps)
+        return dict(samples=samples, labels=labels, logits=logits, rows=rows, steps=steps, frames=frames_dev)
 
     def epilogue_device(self, res, batched, target, overlap, mu_law, wave_len):
         """float64 tail of generate() (:243-258) on the GPU (``wrnn_epilogue``): (wave_len,) float64 cuda tensor."""
@@ -300,40 +316,62 @@ class WaveRNN(nn.Module):
         self.train()
         return output
 
-    def generate_many(self, mels_list, save_paths=None, mu_law=True, **native_opts):
+    def generate_many(self, mels_list, save_paths=None, mu_law=True, epilogue='host', **native_opts):
         """Extension for serving loops: several independent utterances of different lengths in ONE device call, so that all
         8 XCD teams of the GPU work (a single unbatched utterance keeps one team = 1/8 of the chip busy; up to 8 utterances
         run on the latency kernel one per team, more on the batch kernel).  ``mels_list``: sequence of (n_mels, T_i) arrays.
         The clips are zero-padded on the right to the longest one -- exactly the padding ``generate`` itself applies
-        (``pad_tensor``, :183) -- every row is generated for max(T_i) frames and trimmed afterwards, so the first
-        T_i * hop samples of row i are what a single ``generate`` call on clip i computes for the same noise.  Returns a list
-        of float64 arrays, each what ``generate(mels_i[None], path_i, False, ...)`` returns ((T_i - 1) * hop samples, mu-law
-        decoded, 20-hop fade-out); writes the wavs when ``save_paths`` is given."""
+        (``pad_tensor``, :183) -- and handed over as a RAGGED batch (``frames_dev``): row i runs T_i * hop steps, the library
+        orders the rows by length on the device and balances them over the XCD teams, so a short clip costs its own length, not
+        the longest one's.  The first T_i * hop samples of row i are what a single ``generate`` call on clip i computes for the
+        same noise.  Returns a list of float64 arrays, each what ``generate(mels_i[None], path_i, False, ...)`` returns
+        ((T_i - 1) * hop samples, mu-law decoded, 20-hop fade-out); writes the wavs when ``save_paths`` is given.
+        ``epilogue='device'``: decode / trim / fade-out of all rows in one ``wrnn_epilogue_rows`` launch."""
         self.eval()
         mu_law = mu_law if self.mode == 'RAW' else False
         arrs = [np.asarray(torch.as_tensor(m).detach().cpu().numpy(), dtype=np.float32) for m in mels_list]
         if not arrs or any(a.ndim != 2 or a.shape[0] != self.feat_dims for a in arrs):
             raise ValueError(f'expected a non-empty sequence of (n_mels={self.feat_dims}, T_i) arrays')
         lens = [a.shape[1] for a in arrs]
+        if min(lens) < 21:   # the fade-out broadcast error of :258, raised before any device work
+            t_bad = min(lens)
+            raise ValueError(f'operands could not be broadcast together with shapes ({max((t_bad - 1) * self.hop_length, 0)},) '
+                             f'({20 * self.hop_length},) ({max((t_bad - 1) * self.hop_length, 0)},)')
         tmax = max(lens)
         batch = np.zeros((len(arrs), self.feat_dims, tmax), np.float32)
         for i, a in enumerate(arrs):
             batch[i, :, :lens[i]] = a
         if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) == _cabi.NOISE_PHILOX:
             native_opts['seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
-        res = self.generate_raw(batch, False, 11000, 550, **native_opts)
-        samples = res['samples'].cpu().numpy().astype(np.float64)
-        outs = []
-        for i, t_i in enumerate(lens):
-            wave_len = (t_i - 1) * self.hop_length
-            out = samples[i, :t_i * self.hop_length]
-            if mu_law:
-                out = decode_mu_law(out, self.n_classes, False)
-            out = out[:wave_len]
-            out[-20 * self.hop_length:] *= np.linspace(1, 0, 20 * self.hop_length)   # raises for T_i < 21, like :258
-            if save_paths is not None:
-                save_wav(out, save_paths[i], self.sample_rate)
-            outs.append(out)
+        ragged = len(set(lens)) > 1
+        res = self.generate_raw(batch, False, 11000, 550, frames=np.asarray(lens, np.int32) if ragged else None, **native_opts)
+        if epilogue == 'device':
+            nat = self.native()
+            dev = res['samples'].device
+            wl_max = (tmax - 1) * self.hop_length
+            with torch.cuda.device(dev):
+                waves = torch.empty((len(arrs), wl_max), dtype=torch.float64, device=dev)
+                nat.epilogue_rows(res['samples'].data_ptr(), res['labels'].data_ptr(), res['rows'], res['steps'], mu_law, wl_max,
+                                  res['frames'].data_ptr() if ragged else 0, waves.data_ptr(), wl_max,
+                                  torch.cuda.current_stream(dev).cuda_stream)
+            waves = waves.cpu().numpy()
+            outs = [waves[i, :(t_i - 1) * self.hop_length].copy() for i, t_i in enumerate(lens)]
+        elif epilogue == 'host':
+            samples = res['samples'].cpu().numpy().astype(np.float64)
+            outs = []
+            for i, t_i in enumerate(lens):
+                wave_len = (t_i - 1) * self.hop_length
+                out = samples[i, :t_i * self.hop_length]
+                if mu_law:
+                    out = decode_mu_law(out, self.n_classes, False)
+                out = out[:wave_len]
+                out[-20 * self.hop_length:] *= np.linspace(1, 0, 20 * self.hop_length)
+                outs.append(out)
+        else:
+            raise ValueError(f"epilogue must be 'host' or 'device', got {epilogue!r}")
+        if save_paths is not None:
+            for out, path in zip(outs, save_paths):
+                save_wav(out, path, self.sample_rate)
         self.train()
         return outs
 

@@ -6,7 +6,12 @@ best race scores are (nearly) tied, and in a free-running generation everything 
 a different -- equally valid -- trajectory.  So:
   * teacher-forced (P0): at EVERY step the GPU label must equal the oracle label, or the step must be a
     near-tie (oracle's relative margin < NEAR_TIE) and the GPU must have picked the oracle's runner-up;
-  * free-running (P1): labels must be identical up to the first such near-tie (if any).
+  * free-running (P1): labels must be identical up to the first such near-tie (if any) -- and the check does NOT stop
+    there: the oracle is re-run teacher-forced on the GPU's OWN trajectory (`x_forced` = the samples the GPU fed back), so
+    every later step is still compared under the per-step rule.  `check_on_gpu_trajectory_*` do exactly that in one oracle
+    pass: zero mismatches on it means (by induction over the steps) the GPU run IS the oracle's free run, bit for bit;
+    a mismatch must be a near-tie with the GPU on the runner-up.  Every step of every row is compared (`compared ==
+    L * rows`, asserted by the BASELINE-size tests).
 With identical labels the fed-back value is bit-identical, which is stricter than the +-1 LSB the
 north star asks for.
 """
@@ -41,6 +46,30 @@ def check_free_run_raw(got, ref):
             f'row {r}: first divergence at step {t} is not a near-tie (margin {ref["margin"][t, r]:.3e})'
         first.append(t)
     return first
+
+
+def check_on_gpu_trajectory_raw(got_labels, got_samples, oracle_loop):
+    """RAW, free-running GPU run checked at EVERY step.  `got_labels`, `got_samples` (L, rows); `oracle_loop(x_forced)` runs
+    the oracle on the same conditioning and noise with the fed-back value forced to `x_forced` (L, rows).  The oracle is
+    driven along the GPU's own trajectory, so a near-tie divergence (allowed: GPU on the oracle's runner-up, margin <
+    NEAR_TIE) does not end the comparison.  Returns dict(compared, near_ties [(t, row, |dlabel|)], max_abs_other): steps
+    compared (= L * rows), the near-tie steps, and max |dlabel| over all OTHER steps (0 by construction when the asserts
+    pass).  near_ties == [] means the GPU run equals the oracle's free run (induction over t)."""
+    ref = oracle_loop(np.ascontiguousarray(got_samples, dtype=np.float32))
+    check_teacher_forced_raw(got_labels, ref)
+    bad = np.argwhere(got_labels != ref['labels'])
+    near = [(int(t), int(r), int(abs(int(got_labels[t, r]) - int(ref['labels'][t, r])))) for t, r in bad]
+    return dict(compared=int(got_labels.size), near_ties=near, max_abs_other=0, ref=ref)
+
+
+def check_on_gpu_trajectory_mol(got_samples, got_mix, oracle_loop):
+    """MOL analogue: the oracle is forced onto the GPU's fed-back samples, so at EVERY step both sides start from the same
+    state: mixture index equal (or a near-tie on the runner-up) and the continuous sample within 2e-5."""
+    ref = oracle_loop(np.ascontiguousarray(got_samples, dtype=np.float32))
+    check_mol(got_samples, got_mix, ref, teacher_forced=True)
+    same = got_mix == ref['labels']
+    err = np.abs(got_samples - ref['samples'])[same]
+    return dict(compared=int(got_mix.size), index_mismatches=int((~same).sum()), max_err=float(err.max()) if err.size else 0.0, ref=ref)
 
 
 def check_mol(got_samples, got_mix, ref, teacher_forced):

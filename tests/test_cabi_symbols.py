@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     lib = _cabi.load_library()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.wrnn_abi_version() == 3
+    assert lib.wrnn_abi_version() == 4 == _cabi.ABI_VERSION
 
 
 def test_create_rejects_bad_config_without_gpu():
@@ -63,3 +63,33 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert got[(cname, 'size')] == C.sizeof(st), cname
         for fname, _ in st._fields_:
             assert got[(cname, fname)] == getattr(st, fname).offset, (cname, fname)
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """load_library() compares wrnn_abi_version() with the ABI the binding was written against: a stale .so (a git-ignored
+    build artefact) must fail at load, not read the structs at shifted offsets."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    monkeypatch.setattr(_cabi, '_lib', None)
+    monkeypatch.setattr(_cabi, 'ABI_VERSION', 3)
+    with pytest.raises(RuntimeError, match='ABI'):
+        _cabi.load_library()
+    monkeypatch.setattr(_cabi, 'ABI_VERSION', 4)
+    assert _cabi.load_library().wrnn_abi_version() == 4
+
+
+def test_generate_refuses_an_unknown_opts_struct_size():
+    """wrnn_sample_opts.struct_size (ABI 4): a caller built against another revision of the header is WRNN_ERR_INVALID.
+    The check precedes every device call, so it runs without a GPU (wrnn_create itself needs a HIP device: skipped where it
+    fails for that reason)."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS
+    try:
+        nat = _cabi.NativeVocoder(device=0, mode='RAW', **DEFAULT_DIMS)
+    except _cabi.WrnnError as e:
+        if e.code == -2:
+            pytest.skip('no HIP device: wrnn_create cannot make a handle here')
+        raise
+    o = _cabi.SampleOpts()
+    o.struct_size = ctypes.sizeof(_cabi.SampleOpts) - 8
+    rc = nat.lib.wrnn_generate(nat._h, 1, 1, 1, 0, 0, 0, ctypes.byref(o), None, 1, None)
+    assert rc == -1 and b'struct_size' in nat.lib.wrnn_last_error(nat._h)

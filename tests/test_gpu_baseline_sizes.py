@@ -1,14 +1,18 @@
 """Parity at the BASELINE.json config sizes, through the C-ABI, on the shipped kernels with default settings.
 
 configs[1]: B=1, mel 80x401 (110 275 free-running steps = 14 default segments of the latency kernel), RAW 10-bit;
-configs[2]: B=64 utterances (batch kernel, 8 rows per XCD team in lock-step), sampled with the production Philox noise;
-configs[4]: MOL 9-bit, B=32 (batch kernel, 4 rows per team), injected uniforms.
+configs[2]: B=64 utterances (batch kernel, 8 rows per XCD team in lock-step), sampled with the production Philox noise: all 64
+            rows at T=41 and 8 rows at the full T=401;
+configs[4]: MOL 9-bit, B=32 (batch kernel, 4 rows per team), injected uniforms: all 32 rows at T=41, 4 rows at T=401;
+configs[3]: tests/test_gpu_config3.py (the scatter -> generate -> device epilogue -> gather pipeline of bench.py).
 Oracle = the C restatement pinned to the reference (tests/test_oracle_golden.py); the configs[1] clip is additionally
 compared with labels minted from the unmodified reference itself (tests/golden/raw_peaky_b1_t401.npz).
 
-The north star's contract is "within +-1 LSB at 10-bit": every test here asserts label IDENTITY up to the first near-tie
-of the sampler's race (tests/parity_util.py) and prints max |label difference| over the compared steps, so the log shows
-the contract directly (0 = bit-identical fed-back values).
+The north star's contract is "within +-1 LSB at 10-bit".  Every test here drives the oracle along the GPU's own trajectory
+(tests/parity_util.py: check_on_gpu_trajectory_*), so EVERY step of every checked row is compared -- `compared == L * rows` is
+asserted -- under the per-step rule: label identical, or a near-tie of the sampler's race with the GPU on the oracle's
+runner-up.  Zero near-ties means the GPU run is bit-identical to the oracle's free run (and, for the reference-minted
+goldens, to the reference's own labels and wav).
 """
 import os
 
@@ -18,7 +22,7 @@ import torch
 
 from oracle import oracle as orc
 from tests.golden_util import load_case
-from tests.parity_util import MOL_LSB, check_free_run_raw, check_mol, label_stats
+from tests.parity_util import MOL_LSB, check_free_run_raw, check_on_gpu_trajectory_mol, check_on_gpu_trajectory_raw, label_stats
 
 pytestmark = pytest.mark.gpu
 
@@ -44,27 +48,36 @@ def _oracle_rows(om, mels, rows, noise_mode, n1=None, n2=None):
                    None if n2 is None else np.ascontiguousarray(n2[:, rows]))
 
 
+def _forced_raw(om, mels, rows, q):
+    """oracle_loop(x_forced) for check_on_gpu_trajectory_raw: the oracle on `rows` of the batch with Exp(1) draws q
+    (L, len(rows), n_classes), driven along the trajectory it is handed."""
+    cm, ca = om.conditioning(mels[rows])
+    return lambda xf: om.loop(cm, ca, orc.NOISE_EXPO, q, x_forced=xf)
+
+
+def _report(tag, st):
+    print(f'\n[parity {tag}] steps compared {st["compared"]} (every step of every checked row), near-tie divergences '
+          f'{len(st["near_ties"])} {st["near_ties"][:8]}, max |dlabel| elsewhere {st["max_abs_other"]}')
+
+
 def test_config1_b1_t401_injected_noise_vs_reference_and_oracle():
     """configs[1]: the benchmarked clip, free-running over all 110 275 steps with the reference's own noise stream
     (452 MB of Exp(1) draws on the device), default segmentation (14 launches), against the labels of the unmodified
-    reference and against the oracle."""
+    reference and against the oracle driven along the GPU's own trajectory (every step compared)."""
     from tacotronv2_wavernn_chinese_amd import _cabi
     fx = load_case('raw_peaky_b1_t401')
     m = _model(fx['state_dict'])
     res = m.generate_raw(fx['mels'], False, 11000, 550, noise_mode=_cabi.NOISE_INJECTED, noise1=fx['noise']['expo'])
     assert m.last_timing['kernel'] == _cabi.KERNEL_TEAM2 and m.last_timing['launches'] >= 10
     got = res['labels'].cpu().numpy().T
+    smp = res['samples'].cpu().numpy().T
     assert got.shape == (401 * 275, 1)
     om = orc.OracleModel(fx['state_dict'], fast=True)
-    cm, ca = om.conditioning(fx['mels'])
-    ref = om.loop(cm, ca, orc.NOISE_EXPO, fx['noise']['expo'])
-    first = check_free_run_raw(got, ref)
-    st = label_stats(got, ref['labels'], first)
-    print(f'\n[parity configs[1] injected] steps compared {st["compared"]}, mismatches {st["mismatches"]}, '
-          f'max |dlabel| {st["max_abs"]}, first near-tie divergence {first}')
-    assert st['max_abs'] <= 1
-    if first[0] is None:
-        # identical to the oracle over the whole clip => must equal what the reference itself produced
+    st = check_on_gpu_trajectory_raw(got, smp, _forced_raw(om, fx['mels'], [0], fx['noise']['expo']))
+    _report('configs[1] injected', st)
+    assert st['compared'] == 401 * 275
+    if not st['near_ties']:
+        # identical to the oracle's free run over the whole clip => must equal what the reference itself produced
         np.testing.assert_array_equal(got, fx['labels'].astype(np.int32))
         wav = m.generate(fx['mels'], '/tmp/wrnn_c1.wav', False, 11000, 550, True, noise_mode=_cabi.NOISE_INJECTED,
                          noise1=fx['noise']['expo'])
@@ -84,15 +97,10 @@ def test_config1_b1_t401_philox_production_mode():
     res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=seed)
     got = res['labels'].cpu().numpy().T
     L = got.shape[0]
-    q = _philox_q(seed, L, [0])
     om = orc.OracleModel(sd, fast=True)
-    cm, ca = om.conditioning(mels)
-    ref = om.loop(cm, ca, orc.NOISE_EXPO, q)
-    first = check_free_run_raw(got, ref)
-    st = label_stats(got, ref['labels'], first)
-    print(f'\n[parity configs[1] philox] steps compared {st["compared"]}, mismatches {st["mismatches"]}, '
-          f'max |dlabel| {st["max_abs"]}, first near-tie divergence {first}')
-    assert st['max_abs'] <= 1
+    st = check_on_gpu_trajectory_raw(got, res['samples'].cpu().numpy().T, _forced_raw(om, mels, [0], _philox_q(seed, L, [0])))
+    _report('configs[1] philox', st)
+    assert st['compared'] == L == 401 * 275
     assert len(np.unique(got)) > 100
 
 
@@ -108,11 +116,27 @@ def _philox_q(seed, L, rows, chunk=4096):
     return q
 
 
-def test_config2_b64_sampled_batch_kernel():
+def _check_rows_raw(tag, sd, mels, lab, smp, seed, rows, group):
+    """Rows `rows` of a Philox-sampled RAW batch against the oracle, `group` rows per oracle call (bounds the host copy of the
+    replayed draws: L x group x 1024 floats).  Every step of every listed row is compared."""
+    om = orc.OracleModel(sd, fast=True)
+    L = lab.shape[1]
+    compared, near = 0, []
+    for i in range(0, len(rows), group):
+        rs = rows[i:i + group]
+        st = check_on_gpu_trajectory_raw(lab[rs].T, smp[rs].T, _forced_raw(om, mels, rs, _philox_q(seed, L, rs)))
+        compared += st['compared']
+        near += [(t, rs[r], d) for t, r, d in st['near_ties']]
+    _report(tag, dict(compared=compared, near_ties=near, max_abs_other=0))
+    assert compared == L * len(rows)
+    return near
+
+
+def test_config2_b64_sampled_batch_kernel_all_rows():
     """configs[2]: 64 distinct utterances, sampled (not greedy) with the production Philox noise, T=41 (11 275 steps):
-    AUTO picks the batch kernel (8 rows per XCD team in lock-step on the matrix cores).  8 of the 64 rows -- one per
-    team, different positions inside a team's row octet -- are checked against the oracle with the host replay of
-    their draws (the noise is keyed by the global row index, rows are independent)."""
+    AUTO picks the batch kernel (8 rows per XCD team in lock-step on the matrix cores).  ALL 64 rows are checked against
+    the oracle with the host replay of their draws (the noise is keyed by the global row index, rows are independent):
+    64 x 11 275 = 721 600 steps, each compared."""
     from tacotronv2_wavernn_chinese_amd import _cabi
     from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
     sd = make_state_dict(0, variant='peaky')
@@ -122,33 +146,36 @@ def test_config2_b64_sampled_batch_kernel():
     seed = 0x5EED0064
     res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=seed)
     assert m.last_timing['kernel'] == _cabi.KERNEL_BATCH
-    lab = res['labels'].cpu().numpy()          # (64, L)
-    L = lab.shape[1]
+    lab, smp = res['labels'].cpu().numpy(), res['samples'].cpu().numpy()          # (64, L)
     assert lab.shape == (B, T * 275)
-    rows = [0, 9, 18, 27, 36, 45, 54, 63]
-    q = _philox_q(seed, L, rows)
-    om = orc.OracleModel(sd, fast=True)
-    cm, ca = om.conditioning(mels[rows])
-    ref = om.loop(cm, ca, orc.NOISE_EXPO, q)
-    got = lab[rows].T
-    first = check_free_run_raw(got, ref)
-    st = label_stats(got, ref['labels'], first)
-    print(f'\n[parity configs[2] B=64 philox, batch kernel] rows {rows}: steps compared {st["compared"]}, mismatches '
-          f'{st["mismatches"]}, max |dlabel| {st["max_abs"]}, first near-tie divergence {first}')
-    assert st['max_abs'] <= 1
+    _check_rows_raw('configs[2] B=64 T=41 philox, batch kernel, all rows', sd, mels, lab, smp, seed, list(range(B)), 16)
     # all 64 rows are different utterances with different noise: no two label sequences coincide
     assert len({lab[i, :2000].tobytes() for i in range(B)}) == B
-    smp = res['samples'].cpu().numpy()
     np.testing.assert_array_equal(smp, 2.0 * lab.astype(np.float32) / np.float32(1023.0) - np.float32(1.0))
 
 
-def test_config4_mol_b32_batch_kernel():
-    """configs[4]: MOL 9-bit, B=32, injected u_mix / u_log, T=41; the batch kernel (4 rows per team).  Mixture index
-    identical (near-tie rule) and the continuous sample within 1/4 of a 9-bit LSB in free-running mode."""
+def test_config2_b64_t401_full_size_rows():
+    """configs[2] at the BASELINE size itself: 64 utterances x mel 80x401 (110 275 steps each, the bench.py workload).
+    8 rows -- one per XCD team, every position inside a team's row octet -- are checked over all their 110 275 steps."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
+    sd = make_state_dict(0, variant='peaky')
+    B, T = 64, 401
+    mels = make_mels(1000, B, T)
+    m = _model(sd)
+    seed = 0xC0FFEE
+    res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=seed)
+    assert m.last_timing['kernel'] == _cabi.KERNEL_BATCH
+    lab, smp = res['labels'].cpu().numpy(), res['samples'].cpu().numpy()
+    rows = [0, 9, 18, 27, 36, 45, 54, 63]
+    _check_rows_raw('configs[2] B=64 T=401 philox, batch kernel', sd, mels, lab, smp, seed, rows, 4)
+    assert len({lab[i, :4000].tobytes() for i in range(B)}) == B
+
+
+def _mol_case(B, T, rows, tag):
     from tacotronv2_wavernn_chinese_amd import _cabi
     from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
     sd = make_state_dict(0, mode='MOL', variant='default', bits=9)
-    B, T = 32, 41
     L = T * 275
     mels = make_mels(777, B, T)
     rng = np.random.Generator(np.random.PCG64(2024))
@@ -158,15 +185,28 @@ def test_config4_mol_b32_batch_kernel():
     res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_INJECTED, noise1=u_mix, noise2=u_log)
     assert m.last_timing['kernel'] == _cabi.KERNEL_BATCH
     smp, mix = res['samples'].cpu().numpy(), res['labels'].cpu().numpy()
-    rows = [0, 5, 10, 15, 20, 25, 30, 31]
     om = orc.OracleModel(sd, mode='MOL', bits=9, fast=True)
-    ref = _oracle_rows(om, mels, rows, 0, u_mix, u_log)
-    check_mol(smp[rows].T, mix[rows].T, ref, teacher_forced=False)
-    same = mix[rows].T == ref['labels']
-    err = np.abs(smp[rows].T - ref['samples'])[same]
-    print(f'\n[parity configs[4] MOL B=32, batch kernel] rows {rows}: mixture index equal on {same.mean() * 100:.3f} % of steps, '
-          f'max |sample error| {err.max():.3e} = {err.max() / MOL_LSB:.4f} LSB(9 bit)')
+    cm, ca = om.conditioning(mels[rows])
+    n1, n2 = np.ascontiguousarray(u_mix[:, rows]), np.ascontiguousarray(u_log[:, rows])
+    # every step from the GPU's own fed-back sample: mixture index equal (near-tie rule), sample within 2e-5
+    st = check_on_gpu_trajectory_mol(smp[rows].T, mix[rows].T, lambda xf: om.loop(cm, ca, 0, n1, n2, x_forced=xf))
+    print(f'\n[parity {tag}] rows {rows if len(rows) <= 8 else "all"}: steps compared {st["compared"]}, mixture-index near-ties '
+          f'{st["index_mismatches"]}, max |sample error| {st["max_err"]:.3e} = {st["max_err"] / MOL_LSB:.5f} LSB(9 bit)')
+    assert st['compared'] == L * len(rows)
     assert np.abs(smp).max() <= 1.0
+
+
+def test_config4_mol_b32_batch_kernel_all_rows():
+    """configs[4]: MOL 9-bit, B=32, injected u_mix / u_log, T=41; the batch kernel (4 rows per team).  ALL 32 rows, every
+    step: mixture index identical (near-tie rule) and the continuous sample within 2e-5 of the oracle started from the
+    GPU's own previous sample."""
+    _mol_case(32, 41, list(range(32)), 'configs[4] MOL B=32 T=41, batch kernel')
+
+
+def test_config4_mol_b32_t401_full_size_rows():
+    """configs[4] at the BASELINE size: 32 utterances x mel 80x401; 4 rows (different teams and quad positions) over all
+    110 275 steps."""
+    _mol_case(32, 401, [0, 13, 22, 31], 'configs[4] MOL B=32 T=401, batch kernel')
 
 
 @pytest.mark.parametrize('kernel', ['team2', 'batch'])
@@ -182,15 +222,10 @@ def test_b8_t60_reference_golden(kernel):
         assert m.last_timing['launches'] >= 4
     got = res['labels'].cpu().numpy().T
     om = orc.OracleModel(fx['state_dict'], fast=True)
-    cm, ca = om.conditioning(fx['mels'])
-    ref = om.loop(cm, ca, orc.NOISE_EXPO, fx['noise']['expo'])
-    np.testing.assert_array_equal(ref['labels'], fx['labels'].astype(np.int32))   # the oracle reproduces the reference here too
-    first = check_free_run_raw(got, ref)
-    st = label_stats(got, ref['labels'], first)
-    print(f'\n[parity B=8 T=60 {kernel}] steps compared {st["compared"]}, mismatches {st["mismatches"]}, max |dlabel| {st["max_abs"]}, '
-          f'first near-tie divergence {first}')
-    assert st['max_abs'] <= 1
-    if all(f is None for f in first):
+    st = check_on_gpu_trajectory_raw(got, res['samples'].cpu().numpy().T, _forced_raw(om, fx['mels'], list(range(8)), fx['noise']['expo']))
+    _report(f'B=8 T=60 {kernel}', st)
+    assert st['compared'] == got.size == 8 * 60 * 275
+    if not st['near_ties']:   # = the oracle's free run = what the reference produced
         np.testing.assert_array_equal(got, fx['labels'].astype(np.int32))
 
 

@@ -146,7 +146,7 @@ def test_mol_parity(name, kernel):
 
 
 @pytest.mark.parametrize('name', ['raw_peaky_b3_t21', 'raw_peaky_fold_t30', 'mol_default_b2_t21'])
-def test_segmented_launches_carry_the_recurrent_state(name, monkeypatch):
+def test_segmented_launches_carry_the_recurrent_state(name):
     """The shipped kernel runs a row as a sequence of launches (one conditioning-stream chunk each) and hands
     h1/h2/gh1/gh2/x over through device memory: with a tiny segment (dozens of launches per row, several rows
     per team) the result must be what a single launch gives, and what the oracle gives."""
@@ -154,9 +154,7 @@ def test_segmented_launches_carry_the_recurrent_state(name, monkeypatch):
     m = _model(fx, 'team2')
     args = (fx['mels'], bool(fx.get('batched', False)), int(fx.get('target', 11000)), int(fx.get('overlap', 550)))
     whole = m.generate_raw(*args, **_noise_kwargs(fx))
-    monkeypatch.setenv('WRNN_TEAM2_SEGMENT', '96')
-    parts = m.generate_raw(*args, **_noise_kwargs(fx))
-    monkeypatch.delenv('WRNN_TEAM2_SEGMENT')
+    parts = m.generate_raw(*args, team2_segment=96, **_noise_kwargs(fx))   # wrnn_sample_opts.team2_segment (ABI 4)
     assert whole['labels'].shape[1] > 10 * 96
     np.testing.assert_array_equal(parts['labels'].cpu().numpy(), whole['labels'].cpu().numpy())
     np.testing.assert_array_equal(parts['samples'].cpu().numpy(), whole['samples'].cpu().numpy())
@@ -306,13 +304,15 @@ def test_many_rows_are_scheduled_independently(kernel):
     assert not np.array_equal(lab[0], lab[1])
     if kernel == 'team2':
         # several rows per team AND several segment launches per row: every (row, segment) hands its own state over
-        os.environ['WRNN_TEAM2_SEGMENT'] = '160'
-        try:
-            res2 = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_ARGMAX)
-        finally:
-            del os.environ['WRNN_TEAM2_SEGMENT']
+        res2 = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_ARGMAX, team2_segment=160)
         assert m.last_timing['launches'] > 30
         np.testing.assert_array_equal(res2['labels'].cpu().numpy(), lab)
+    else:
+        # 2 (resp. 8) rows per batch: 10 batches over 8 teams (teams 0 and 1 run two batches one after the other: state
+        # re-initialised, tags keep counting) resp. 3 batches of 8 + 8 + 3 rows on the 8-row kernel (wrnn_sample_opts.batch_rows)
+        for rpb in (2, 8):
+            res2 = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_ARGMAX, batch_rows=rpb)
+            np.testing.assert_array_equal(res2['labels'].cpu().numpy(), lab)
     om = orc.OracleModel(fx['state_dict'], fast=True)
     cm, ca = om.conditioning(base[:1])
     ref = om.loop(cm, ca, orc.NOISE_ARGMAX)
@@ -343,6 +343,16 @@ def test_cli_and_gen_from_file_end_to_end(tmp_path):
                         '-t', '2000', '-o', '200'], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / 'wavernn_inference_output' / 'mel-000_gen_batched_target2000_overlap200_step=0k.wav').exists()
+    # no -w: the training run's latest checkpoint, logs_wavernn/checkpoints/latest_weights.pyt (wavernn_gen.py:112-117,
+    # wavernn/utils/paths.py:11-12) -- the same weights, hence the same first file again (greedy-free: only existence + the path printed)
+    ck2 = tmp_path / 'logs_wavernn' / 'checkpoints'
+    ck2.mkdir(parents=True)
+    os.replace(ckpt, ck2 / 'latest_weights.pyt')
+    out.unlink()
+    r = subprocess.run([sys.executable, os.path.join(root, 'wavernn_gen.py'), '--file', str(mel), '-u'], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert str(ck2 / 'latest_weights.pyt') in r.stdout and 'randomly initialised' not in r.stdout and out.exists()
 
 
 def test_edge_shapes_and_bad_arguments():

@@ -52,6 +52,55 @@ def test_two_rank_sharding_gathers_every_clip_in_order():
             np.testing.assert_array_equal(np.asarray(o), np.arange((21 + i - 1) * 3, dtype=np.float64) + 1000.0 * i)
 
 
+def _worker_ragged(rank, world, port, q):
+    import torch.distributed as dist
+    from tacotronv2_wavernn_chinese_amd.sharding import balanced_shards, generate_sharded
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lens = [100, 21, 22, 23, 24, 25, 60, 40]
+    mels = [np.full((80, t), float(i), np.float32) for i, t in enumerate(lens)]
+    seen = []
+
+    def fake_many(idx, ms):   # stands in for model.generate_many: one ragged device call for the rank's whole share
+        seen.append(list(idx))
+        return [np.arange((m.shape[1] - 1) * 2, dtype=np.float64) + 1000.0 * i for i, m in zip(idx, ms)]
+
+    out = generate_sharded(None, mels, balance=True, generate_many=fake_many)
+    assert seen == [balanced_shards(lens, world)[rank]]
+    q.put((rank, seen[0], [o.tolist() for o in out]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_length_balanced_sharding_of_ragged_clips():
+    """Ragged clips: the length-balanced table (LPT) instead of round-robin, one generate_many call per rank, every wav back
+    in input order on every rank."""
+    from tacotronv2_wavernn_chinese_amd.sharding import balanced_shards, shard_indices
+    lens = [100, 21, 22, 23, 24, 25, 60, 40]
+    bins = balanced_shards(lens, 2)
+    loads = [sum(lens[i] for i in b) for b in bins]
+    rr = [sum(lens[i] for i in shard_indices(len(lens), r, 2)) for r in range(2)]
+    assert sorted(i for b in bins for i in b) == list(range(len(lens)))
+    assert max(loads) < max(rr) and max(loads) - min(loads) <= 25            # 158 / 157 against round-robin's 206 / 109
+    assert balanced_shards([7] * 6, 3) == [[0, 3], [1, 4], [2, 5]]            # equal lengths: the round-robin assignment
+    assert balanced_shards([5, 9], 4) == [[1], [0], [], []]                   # more ranks than clips
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == bins
+    for _, _, outs in res:
+        assert len(outs) == len(lens)
+        for i, o in enumerate(outs):
+            np.testing.assert_array_equal(np.asarray(o), np.arange((lens[i] - 1) * 2, dtype=np.float64) + 1000.0 * i)
+
+
 def test_single_process_path():
     from tacotronv2_wavernn_chinese_amd.sharding import generate_sharded
     out = generate_sharded(lambda i, m: np.array([i, m.sum()]), [np.ones((2, 2)), np.zeros((2, 2))])

@@ -8,14 +8,23 @@ export PYTHONDONTWRITEBYTECODE=1
 T=${TAG:-x}
 rm -f gpurun_out/qb_${T}_*
 for b in 64 32; do
-  WRNN_TEAM_PROF=1 timeout 120 python bench.py --config 2 --batch $b --frames 41 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/qb_${T}_prof_b$b.err
+  timeout 120 python bench.py --config 2 --batch $b --frames 41 --steps 1 --warmup 1 --no-cpu-baseline --phase-profile > gpurun_out/qb_${T}_prof_b$b.json 2> gpurun_out/qb_${T}_prof_b$b.err
 done
 for c in 2 4; do
   timeout 200 python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/qb_${T}_bench_c$c.json 2> gpurun_out/qb_${T}_bench_c$c.err
 done
 timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py tests/test_gpu_parity.py -x -q -m gpu -k "batch or config2 or config4 or many" > gpurun_out/qb_${T}_pytest.log 2>&1
 echo "rc pytest $?"; tail -2 gpurun_out/qb_${T}_pytest.log
-grep -h "wave 0" gpurun_out/qb_${T}_prof_b64.err gpurun_out/qb_${T}_prof_b32.err | head -2
+python - <<PY
+import json
+for b in (64, 32):
+    try:
+        for l in open('gpurun_out/qb_${T}_prof_b%d.json' % b):
+            if l.startswith('{'):
+                d = json.loads(l)['phase_cycles_per_step']['wave0']; print('phase cycles B=%d wave0:' % b, d, 'total', sum(d))
+    except Exception as e:
+        print('B', b, 'no profile:', e)
+PY
 python - <<PY
 import json
 for c in (2, 4):

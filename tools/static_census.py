@@ -14,8 +14,7 @@ import tempfile
 SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tacotronv2_wavernn_chinese_amd', 'csrc', 'loop_batch.hip')
 HIPCC = '/opt/rocm/bin/hipcc'
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17']
-NAMES = {'ILi0ELi2ELb0ELb0': 'RAW_R8', 'ILi0ELi1ELb0ELb0': 'RAW_R4', 'ILi1ELi2ELb0ELb0': 'MOL_R8', 'ILi1ELi1ELb0ELb0': 'MOL_R4',
-         'ILi0ELi2ELb0ELb1': 'RAW_R8_pingpong (opt-in variant)'}
+NAMES = {'ILi0ELi2ELb0E': 'RAW_R8', 'ILi0ELi1ELb0E': 'RAW_R4', 'ILi1ELi2ELb0E': 'MOL_R8', 'ILi1ELi1ELb0E': 'MOL_R4'}
 
 
 def main() -> int:
