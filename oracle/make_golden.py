@@ -45,7 +45,56 @@ FORWARD_CASES = [
     dict(name='fwd_raw_peaky_b2_t6', mode='RAW', bits=10, variant='peaky', B=2, T=6),
     dict(name='fwd_mol_default_b2_t6', mode='MOL', bits=9, variant='default', B=2, T=6),
 ]
+# One training iteration (`python -m oracle.make_golden train`): forward in train() mode (BatchNorm on batch statistics), loss,
+# loss.backward() -- the loss and, per parameter, the gradient's L2 norm + a strided sample of it (the full gradients are 17 MB)
+TRAIN_CASES = [
+    dict(name='train_raw_peaky_b4_t5', mode='RAW', bits=10, variant='peaky', B=4, T=5),
+    dict(name='train_mol_default_b4_t5', mode='MOL', bits=9, variant='default', B=4, T=5),
+]
+TRAIN_GRAD_SAMPLES = 257
 WEIGHT_SEED, MEL_SEED, NOISE_SEED = 0, 1234, 42
+
+
+def train_inputs(c):
+    """Seeded (x, mels, y) of a training fixture: rebuilt identically wherever the fixture is replayed."""
+    B, T, pad, hop = c['B'], c['T'], 2, 275
+    L = T * hop
+    mels = make_mels(MEL_SEED, B, T + 2 * pad)
+    rng = np.random.Generator(np.random.PCG64(NOISE_SEED + 1))
+    if c['mode'] == 'RAW':
+        lab = rng.integers(0, 2 ** c['bits'], size=(B, L + 1))
+        x = (2.0 * lab[:, :-1] / (2 ** c['bits'] - 1.0) - 1.0).astype(np.float32)     # the dataset's x / y: a signal and its shift
+        y = lab[:, 1:].astype(np.int64)
+    else:
+        sig = rng.uniform(-1.0, 1.0, size=(B, L + 1)).astype(np.float32)
+        sig[0, 1:8] = [-1.0, -0.9995, 0.9995, 1.0, 0.0, 0.5, -0.5]                      # the edge branches of the discretised likelihood
+        x, y = sig[:, :-1].copy(), sig[:, 1:].copy()
+    return x, mels, y
+
+
+def grad_digest(g: np.ndarray) -> dict:
+    flat = np.asarray(g, np.float32).reshape(-1)
+    idx = np.linspace(0, flat.size - 1, min(TRAIN_GRAD_SAMPLES, flat.size)).astype(np.int64)
+    return dict(norm=np.float64(np.sqrt(np.sum(flat.astype(np.float64) ** 2))), idx=idx, val=flat[idx])
+
+
+def mint_train():
+    from oracle import ref_harness as rh
+    for c in TRAIN_CASES:
+        sd = make_state_dict(WEIGHT_SEED, mode=c['mode'], variant=c['variant'], bits=c['bits'])
+        model = rh.build_reference_model(sd, mode=c['mode'], bits=c['bits'])
+        x, mels, y = train_inputs(c)
+        out = rh.reference_train_step(model, x, mels, y)
+        fix = dict(mode=c['mode'], bits=c['bits'], variant=c['variant'], B=c['B'], T=c['T'], weight_seed=WEIGHT_SEED, mel_seed=MEL_SEED,
+                   xy_seed=NOISE_SEED + 1, loss=np.float64(out['loss']), logits_sub=out['logits'][:, ::97].astype(np.float32), sub_stride=97,
+                   keys=np.array(sorted(out['grads'])))
+        for k, g in out['grads'].items():
+            dg = grad_digest(g)
+            fix['norm/' + k], fix['idx/' + k], fix['val/' + k] = dg['norm'], dg['idx'], dg['val']
+        path = os.path.join(GOLDEN_DIR, c['name'] + '.npz')
+        np.savez_compressed(path, **fix)
+        print(f"{c['name']}: loss {out['loss']:.6f}, {len(out['grads'])} gradients -> {os.path.getsize(path) / 1024:.0f} KiB")
+
 
 
 def mint_forward():
@@ -81,6 +130,9 @@ def main() -> int:
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'forward':
         mint_forward()
+        return 0
+    if len(sys.argv) > 1 and sys.argv[1] == 'train':
+        mint_train()
         return 0
     cases = LONG_CASES if (len(sys.argv) > 1 and sys.argv[1] == 'long') else CASES
     for c in cases:

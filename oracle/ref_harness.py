@@ -175,6 +175,27 @@ def reference_forward(model, x: np.ndarray, mels_padded: np.ndarray, y: np.ndarr
     return out
 
 
+def reference_train_step(model, x: np.ndarray, mels_padded: np.ndarray, y: np.ndarray) -> dict:
+    """One iteration of the reference's training loop body (wavernn_train.py:103-122) on the unmodified module in train()
+    mode: y_hat = model(x, m), the loss, loss.backward().  Returns the loss, the fc3 outputs and every parameter gradient."""
+    import torch
+    import torch.nn.functional as F
+    ref = load_reference()
+    model.train()
+    model.zero_grad()
+    xt = torch.from_numpy(np.ascontiguousarray(x))
+    mt = torch.from_numpy(np.ascontiguousarray(mels_padded))
+    yt = torch.from_numpy(np.ascontiguousarray(y))
+    y_hat = model(xt, mt)
+    if model.mode == 'RAW':
+        loss = F.cross_entropy(y_hat.transpose(1, 2).unsqueeze(-1), yt.long().unsqueeze(-1))
+    else:
+        loss = ref.dist.discretized_mix_logistic_loss(y_hat, yt.float().unsqueeze(-1))
+    loss.backward()
+    grads = {k: p.grad.detach().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+    return dict(loss=float(loss.detach()), logits=y_hat.detach().numpy(), grads=grads)
+
+
 def replay_noise(seed: int, mode: str, steps: int, rows: int, n_classes: int = 1024,
                  rnn_dims: int = 512, aux_dims: int = 32) -> dict:
     """See oracle/noise.py (kept there so the GPU box can replay without the reference)."""

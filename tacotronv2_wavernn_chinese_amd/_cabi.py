@@ -29,7 +29,7 @@ ABI_VERSION = 4   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding w
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
                     'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_rows', 'wrnn_epilogue_tables', 'wrnn_loss',
-                    'wrnn_phase_profile', 'wrnn_phase_cycles',
+                    'wrnn_phase_profile', 'wrnn_phase_cycles', 'wrnn_train_step',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
                     'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
 
@@ -71,6 +71,18 @@ class SampleOpts(C.Structure):
                 ('seed', C.c_uint64), ('noise1_dev', C.c_void_p), ('noise2_dev', C.c_void_p), ('x_forced_dev', C.c_void_p),
                 ('logits_out_dev', C.c_void_p), ('x_init_dev', C.c_void_p), ('frames_dev', C.c_void_p),
                 ('batch_rows', C.c_int32), ('team2_segment', C.c_int32)]
+
+
+LOOP_PARAM_FIELDS = ('I_w', 'I_b', 'rnn1_w_ih', 'rnn1_w_hh', 'rnn1_b_ih', 'rnn1_b_hh', 'rnn2_w_ih', 'rnn2_w_hh', 'rnn2_b_ih',
+                     'rnn2_b_hh', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc3_b')
+# wrnn_loop_params field -> state_dict key of the reference module (fatchord_version.py:115-123)
+LOOP_PARAM_KEYS = ('I.weight', 'I.bias', 'rnn1.weight_ih_l0', 'rnn1.weight_hh_l0', 'rnn1.bias_ih_l0', 'rnn1.bias_hh_l0',
+                   'rnn2.weight_ih_l0', 'rnn2.weight_hh_l0', 'rnn2.bias_ih_l0', 'rnn2.bias_hh_l0', 'fc1.weight', 'fc1.bias',
+                   'fc2.weight', 'fc2.bias', 'fc3.weight', 'fc3.bias')
+
+
+class LoopParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in LOOP_PARAM_FIELDS]
 
 
 class Timing(C.Structure):
@@ -140,6 +152,9 @@ def load_library() -> C.CDLL:
     lib.wrnn_phase_profile.restype = C.c_int
     lib.wrnn_phase_cycles.argtypes = [vp, C.POINTER(C.c_double)]
     lib.wrnn_phase_cycles.restype = C.c_int
+    lib.wrnn_train_step.argtypes = [vp, C.POINTER(LoopParams), C.POINTER(LoopParams), vp, vp, vp, vp, C.c_int32, C.c_int64, vp, vp,
+                                    vp, vp, vp]
+    lib.wrnn_train_step.restype = C.c_int
     lib.wrnn_epilogue_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.wrnn_epilogue_tables.restype = C.c_int
     lib.wrnn_loss.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
@@ -291,6 +306,16 @@ class NativeVocoder:
         out = np.zeros(8 * 32, np.float64)
         self._check(self.lib.wrnn_phase_cycles(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out.reshape(8, 32)
+
+    def train_step(self, w_ptrs, g_ptrs, x_ptr: int, mels_up_ptr: int, aux_ptr: int, y_ptr: int, B: int, L: int, loss_ptr: int,
+                   logits_ptr: int, d_mels_up_ptr: int, d_aux_ptr: int, stream: int):
+        """``wrnn_train_step``: w_ptrs / g_ptrs = sequences of 16 device pointers in ``LOOP_PARAM_FIELDS`` order (g_ptrs may be
+        None: forward + loss only)."""
+        w = LoopParams(*[int(p) for p in w_ptrs])
+        g = LoopParams(*[int(p) for p in g_ptrs]) if g_ptrs is not None else None
+        self._check(self.lib.wrnn_train_step(self._h, C.byref(w), C.byref(g) if g is not None else None, x_ptr, mels_up_ptr, aux_ptr,
+                                             y_ptr or None, int(B), int(L), loss_ptr or None, logits_ptr or None,
+                                             d_mels_up_ptr or None, d_aux_ptr or None, stream or None))
 
     def loss(self, y_hat_ptr: int, y_ptr: int, n_rows: int, out_ptr: int, stream: int):
         self._check(self.lib.wrnn_loss(self._h, y_hat_ptr, y_ptr, int(n_rows), out_ptr, stream or None))

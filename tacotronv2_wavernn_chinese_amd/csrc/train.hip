@@ -39,7 +39,17 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) sgemm_kernel(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
                                                     float *__restrict__ C, long ldc, int M, int N, int K, int beta,
-                                                    const float *__restrict__ bias, int relu) {
+                                                    const float *__restrict__ bias, int relu, int kper, long cslice) {
+    // split K (weight gradients: K = B*L, small output): blockIdx.z owns k in [z * kper, (z + 1) * kper) and writes its partial
+    // product to C + z * cslice; kper == 0: the whole K range
+    if (kper > 0) {
+        const long k_lo = (long)blockIdx.z * kper;
+        A += TA ? k_lo * lda : k_lo;
+        B += TB ? k_lo : k_lo * ldb;
+        C += (long)blockIdx.z * cslice;
+        K = K - k_lo < kper ? (int)(K - k_lo) : kper;
+        if (K < 0) K = 0;
+    }
     __shared__ float As[GT_K][GT_LD];
     __shared__ float Bs[GT_K][GT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,13 +137,13 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const float *__restrict__ A,
 }
 
 hipError_t gemm(hipStream_t s, bool ta, bool tb, const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K,
-                int beta = 0, const float *bias = nullptr, int relu = 0) {
+                int beta = 0, const float *bias = nullptr, int relu = 0, int slices = 1, int kper = 0, long cslice = 0) {
     if (M <= 0 || N <= 0) return hipSuccess;
-    dim3 grid((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M);
-    if (ta && tb) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
-    else if (ta) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
-    else if (tb) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
-    else hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu);
+    dim3 grid((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M, slices);
+    if (ta && tb) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu, kper, cslice);
+    else if (ta) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu, kper, cslice);
+    else if (tb) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu, kper, cslice);
+    else hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, beta, bias, relu, kper, cslice);
     return hipGetLastError();
 }
 
@@ -158,17 +168,37 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
     for (int i = ty; i < 32; i += 8)
         if (bx + i < rows && by + tx < cols) dst[(size_t)(bx + i) * cols + by + tx] = t[tx][i];
 }
-// out[n] = sum_m A[m * lda + n]: one workgroup per 64 columns, fixed summation order (4 row lanes, then 4 partials)
-__global__ void __launch_bounds__(256) col_sum_kernel(const float *__restrict__ A, long lda, long M, int N, float *__restrict__ out) {
-    __shared__ double part[4][64];
+// out[n] = sum_m A[m * lda + n] in two stages with a fixed summation order: CS_CHUNKS row chunks x 64-column blocks of partial sums
+// (double), then one thread per column adds the chunks in order.
+#define CS_CHUNKS 64
+__global__ void __launch_bounds__(256) col_sum_part_kernel(const float *__restrict__ A, long lda, long M, int N, double *__restrict__ part) {
+    __shared__ double sh[4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const long per = (M + CS_CHUNKS - 1) / CS_CHUNKS, m_lo = (long)blockIdx.y * per, m_hi = m_lo + per < M ? m_lo + per : M;
     double acc = 0.0;
     if (n < N)
-        for (long m = rl; m < M; m += 4) acc += (double)A[m * lda + n];
-    part[rl][c] = acc;
+        for (long m = m_lo + rl; m < m_hi; m += 4) acc += (double)A[m * lda + n];
+    sh[rl][c] = acc;
     __syncthreads();
-    if (rl == 0 && n < N) out[n] = (float)((part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+    if (rl == 0 && n < N) part[(size_t)blockIdx.y * N + n] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+}
+__global__ void __launch_bounds__(256) col_sum_final_kernel(const double *__restrict__ part, int N, float *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double acc = 0.0;
+    for (int c = 0; c < CS_CHUNKS; ++c) acc += part[(size_t)c * N + n];
+    out[n] = (float)acc;
+}
+// split-K epilogue: C = (beta) C + sum over slices (fixed order) of P[s]
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restrict__ P, int S, long MN, int N, float *__restrict__ C, long ldc,
+                                                            int beta) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float acc = 0.0f;
+    for (int sl = 0; sl < S; ++sl) acc += P[(size_t)sl * MN + i];
+    const long m = i / N, n = i - m * N;
+    C[m * ldc + n] = beta ? C[m * ldc + n] + acc : acc;
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -179,23 +209,38 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 // grid (H / 4, ceil(B / 32)), block 256: wave u = hidden unit j0 + u, lane = (K half kh, batch row b).
 #define GR_UW 4
 #define GR_HLD(H) ((H) + 4)
+// HT = rnn_dims at compile time (the reference's 512: every load loop unrolls, all loads of a phase are in flight at once --
+// measured 14 -> ~4 us per step against run-time trip counts, whose loop issues one L2 round trip per iteration); HT = 0: any H
+template <int HT>
 __global__ void __launch_bounds__(256) gru_fwd_step_kernel(const float *__restrict__ GI, const float *__restrict__ Whh, const float *__restrict__ bhh,
                                                            float *__restrict__ Hs /* (B, L, H) h_t */, float *__restrict__ HP /* (B, L, H) h_{t-1} */,
                                                            float *__restrict__ Rs, float *__restrict__ Zs, float *__restrict__ Ns,
-                                                           float *__restrict__ GHN, int B, long L, int H, long t) {
+                                                           float *__restrict__ GHN, int B, long L, int Hrt, long t) {
+    const int H = HT ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *hs = sm;                                    // [32][H + 4]
     float *ws = sm + 32 * GR_HLD(H);                   // [3 gates][4 units][H]
     const int tid = threadIdx.x;
     const int j0 = blockIdx.x * GR_UW, b0 = blockIdx.y * 32;
     const int hld = GR_HLD(H);
-    for (int i = tid; i < 32 * H; i += 256) {
-        const int b = i / H, k = i - b * H;
-        hs[b * hld + k] = (b0 + b < B) ? HP[((size_t)(b0 + b) * L + t) * H + k] : 0.0f;
-    }
-    for (int i = tid; i < 3 * GR_UW * H; i += 256) {
-        const int row = i / H, k = i - row * H;        // row = g * 4 + u
-        ws[i] = Whh[((size_t)(row >> 2) * H + j0 + (row & 3)) * H + k];
+    {
+        // h_{t-1} rows and the 12 weight rows as float4, one wave per row, lanes over the row (coalesced, no index division)
+        const int wv = tid >> 6, ln = tid & 63, h4 = H / 4;
+#pragma unroll
+        for (int b = wv; b < 32; b += 4) {
+            const float4 *src = (const float4 *)(HP + ((size_t)(b0 + b) * L + t) * H);
+            float4 *dst = (float4 *)(hs + b * hld);
+            const bool ok = b0 + b < B;
+#pragma unroll
+            for (int c = ln; c < h4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int row = wv; row < 3 * GR_UW; row += 4) {   // row = g * 4 + u
+            const float4 *src = (const float4 *)(Whh + ((size_t)(row >> 2) * H + j0 + (row & 3)) * H);
+            float4 *dst = (float4 *)(ws + row * H);
+#pragma unroll
+            for (int c = ln; c < h4; c += 64) dst[c] = src[c];
+        }
     }
     __syncthreads();
     const int u = tid >> 6, kh = (tid >> 5) & 1, b = tid & 31;
@@ -205,6 +250,7 @@ __global__ void __launch_bounds__(256) gru_fwd_step_kernel(const float *__restri
     const float4 *wz = (const float4 *)(ws + (1 * GR_UW + u) * H + kh * kq);
     const float4 *wn = (const float4 *)(ws + (2 * GR_UW + u) * H + kh * kq);
     float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll 8
     for (int k = 0; k < kq / 4; ++k) {
         const float4 hv = hp[k], a = wr[k], c = wz[k], d = wn[k];
         ar = fmaf(a.w, hv.w, fmaf(a.z, hv.z, fmaf(a.y, hv.y, fmaf(a.x, hv.x, ar))));
@@ -233,11 +279,13 @@ __global__ void __launch_bounds__(256) gru_fwd_step_kernel(const float *__restri
 // dGI_t = [dpr, dpz, dpn]   dGH_t = [dpr, dpz, dpn r]   CD_t = dH z      (dGI / dGH feed the batched weight / input GEMMs)
 // WhhT = W_hh transposed, [H][3H]: the workgroup's 4 units are 4 contiguous rows.  Same grid / thread map as the forward step.
 #define GB_KC 768
+template <int HT>
 __global__ void __launch_bounds__(256) gru_bwd_step_kernel(const float *__restrict__ dHext, const float *__restrict__ WhhT,
                                                            const float *__restrict__ HP, const float *__restrict__ Rs, const float *__restrict__ Zs,
                                                            const float *__restrict__ Ns, const float *__restrict__ GHN, float *__restrict__ dGI,
-                                                           float *__restrict__ dGH, float *__restrict__ CD /* (B, H) */, int B, long L, int H,
+                                                           float *__restrict__ dGH, float *__restrict__ CD /* (B, H) */, int B, long L, int Hrt,
                                                            long t) {
+    const int H = HT ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *gs = sm;                                    // [32][GB_KC + 4] chunk of dGH_{t+1}
     float *ws = sm + 32 * (GB_KC + 4);                 // [4 units][3H]
@@ -247,19 +295,31 @@ __global__ void __launch_bounds__(256) gru_bwd_step_kernel(const float *__restri
     const int G = 3 * H;
     float carry = 0.0f;
     if (t + 1 < L) {
-        for (int i = tid; i < GR_UW * G; i += 256) ws[i] = WhhT[(size_t)j0 * G + i];
+        const int wv = tid >> 6, ln = tid & 63;
+        {
+            const float4 *src = (const float4 *)(WhhT + (size_t)(j0 + wv) * G);   // wave u stages its own unit's row
+            float4 *dst = (float4 *)(ws + wv * G);
+#pragma unroll
+            for (int c = ln; c < G / 4; c += 64) dst[c] = src[c];
+        }
         float acc = 0.0f;
+#pragma unroll
         for (int c0 = 0; c0 < G; c0 += GB_KC) {
             const int cw = G - c0 < GB_KC ? G - c0 : GB_KC;
             __syncthreads();
-            for (int i = tid; i < 32 * cw; i += 256) {
-                const int bb = i / cw, k = i - bb * cw;
-                gs[bb * (GB_KC + 4) + k] = (b0 + bb < B) ? dGH[((size_t)(b0 + bb) * L + t + 1) * G + c0 + k] : 0.0f;
+#pragma unroll
+            for (int bb = wv; bb < 32; bb += 4) {
+                const float4 *src = (const float4 *)(dGH + ((size_t)(b0 + bb) * L + t + 1) * G + c0);
+                float4 *dst = (float4 *)(gs + bb * (GB_KC + 4));
+                const bool ok = b0 + bb < B;
+#pragma unroll
+                for (int c = ln; c < cw / 4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
             const int half = cw / 2;                   // cw is a multiple of 8 for the supported dims (3H, H % 8 == 0)
             const float4 *gp = (const float4 *)(gs + b * (GB_KC + 4) + kh * half);
             const float4 *wp = (const float4 *)(ws + u * G + c0 + kh * half);
+#pragma unroll 8
             for (int k = 0; k < half / 4; ++k) {
                 const float4 gv = gp[k], wv = wp[k];
                 acc = fmaf(wv.w, gv.w, fmaf(wv.z, gv.z, fmaf(wv.y, gv.y, fmaf(wv.x, gv.x, acc))));
@@ -458,6 +518,9 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
         oG[i][6] = take(nH); oG[i][7] = take(nG); oG[i][8] = take(nG); oG[i][9] = take((size_t)B * H); oG[i][10] = take((size_t)H * G);
     }
     const size_t odY = take(nY), odF2 = take(nF), odF1 = take(nF), odX3 = take(nH), odX2 = take(nH), odXI = take(nH);
+    const int maxN = G > NC ? G : NC;
+    const size_t sk_floats = (size_t)16 * G * (H + A);                      // split-K partial products (<= 16 slices of the largest dW)
+    const size_t oCS = take((size_t)2 * CS_CHUNKS * maxN), oSK = take(sk_floats);
     const bool fresh = need > st->ws_floats;
     if (fresh) {
         if (st->ws) (void)hipFree(st->ws);
@@ -471,6 +534,8 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     for (int i = 0; i < 2; ++i)
         gr[i] = Gru{ws + oG[i][0], ws + oG[i][1], ws + oG[i][2], ws + oG[i][3], ws + oG[i][4], ws + oG[i][5], ws + oG[i][6], ws + oG[i][7],
                     ws + oG[i][8], ws + oG[i][9], ws + oG[i][10]};
+    double *cs_part = (double *)(ws + oCS);
+    float *sk_part = ws + oSK;
     float *dY = ws + odY, *dF2 = ws + odF2, *dF1 = ws + odF1, *dX3 = ws + odX3, *dX2 = ws + odX2, *dXI = ws + odXI;
     const float *whh[2] = {w->rnn1_w_hh, w->rnn2_w_hh}, *bhh[2] = {w->rnn1_b_hh, w->rnn2_b_hh};
     // the step graphs bake buffer and weight addresses: rebuild when the problem or the parameter storage changed
@@ -480,8 +545,10 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     for (int i = 0; i < 2; ++i) { st->w_hh[i] = whh[i]; st->b_hh[i] = bhh[i]; }
     (void)hipGetLastError();
     const size_t lds_f = (size_t)(32 * GR_HLD(H) + 3 * GR_UW * H) * sizeof(float), lds_b = (size_t)(32 * (GB_KC + 4) + GR_UW * G) * sizeof(float);
-    T_TRY(hipFuncSetAttribute((const void *)gru_fwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-    T_TRY(hipFuncSetAttribute((const void *)gru_bwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    auto *fwd_k = H == 512 ? gru_fwd_step_kernel<512> : gru_fwd_step_kernel<0>;
+    auto *bwd_k = H == 512 ? gru_bwd_step_kernel<512> : gru_bwd_step_kernel<0>;
+    T_TRY(hipFuncSetAttribute((const void *)fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+    T_TRY(hipFuncSetAttribute((const void *)bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     const dim3 sgrid(H / GR_UW, (B + 31) / 32);
     const float *a1 = aux_dev, *a2 = aux_dev + A, *a3 = aux_dev + 2 * A, *a4 = aux_dev + 3 * A;   // aux channel split (:198-199)
 
@@ -496,7 +563,7 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
         if (e != hipSuccess) return e;
         return run_steps(st, &st->g_fwd[i], rebuild, s, [&](hipStream_t cs) {
             for (long t = 0; t < L; ++t)
-                hipLaunchKernelGGL(gru_fwd_step_kernel, sgrid, dim3(256), lds_f, cs, q.GI, whh[i], bhh[i], q.H, q.HP, q.R, q.Z, q.N, q.GHN, B, L, H, t);
+                hipLaunchKernelGGL(fwd_k, sgrid, dim3(256), lds_f, cs, q.GI, whh[i], bhh[i], q.H, q.HP, q.R, q.Z, q.N, q.GHN, B, L, H, t);
         });
     };
     // rnn1 (:152-153)
@@ -526,24 +593,39 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
         hipLaunchKernelGGL(mol_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, Y, (const float *)y_dev, NC / 3, M, 65536.0f,
                            -32.23619130191664f, inv_n, dY);
     auto colsum = [&](const float *Am, long lda, int N, float *out) {
-        hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64), dim3(256), 0, s, Am, lda, M, N, out);
+        hipLaunchKernelGGL(col_sum_part_kernel, dim3((N + 63) / 64, CS_CHUNKS), dim3(256), 0, s, Am, lda, M, N, cs_part);
+        hipLaunchKernelGGL(col_sum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, cs_part, N, out);
+    };
+    // weight gradients dW = dOut^T . In contract over all B*L rows with a small output: split K over slices so that the launch fills
+    // the chip, partial products summed in slice order (deterministic)
+    auto gemm_tn = [&](const float *Am, long lda, const float *Bm, long ldb, float *Cm, long ldc, int Mo, int No) -> hipError_t {
+        const int tiles = ((Mo + GT_M - 1) / GT_M) * ((No + GT_N - 1) / GT_N);
+        int S = tiles >= 128 ? 1 : (256 + tiles - 1) / tiles;
+        if (S > 16) S = 16;
+        if (S <= 1 || (size_t)S * Mo * No > sk_floats) return gemm(s, true, false, Am, lda, Bm, ldb, Cm, ldc, Mo, No, (int)M);
+        const long per = ((M + S - 1) / S + GT_K - 1) / GT_K * GT_K;
+        // one launch, blockIdx.z = slice (slices past the end of K write zeros)
+        hipError_t e = gemm(s, true, false, Am, lda, Bm, ldb, sk_part, No, Mo, No, (int)M, 0, nullptr, 0, S, (int)per, (long)Mo * No);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)Mo * No + 255) / 256)), dim3(256), 0, s, sk_part, S, (long)Mo * No, No, Cm, ldc, 0);
+        return hipGetLastError();
     };
     const unsigned eb_f = (unsigned)((nF + 255) / 256);
     // fc3
-    T_TRY(gemm(s, true, false, dY, NC, F2, FC, g->fc3_w, FC, NC, FC, (int)M));
+    T_TRY(gemm_tn(dY, NC, F2, FC, g->fc3_w, FC, NC, FC));
     colsum(dY, NC, NC, g->fc3_b);
     T_TRY(gemm(s, false, false, dY, NC, w->fc3_w, FC, dF2, FC, M, FC, NC));
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(eb_f), dim3(256), 0, s, dF2, F2, (long)nF);
     // fc2 over cat[F1, a4]
-    T_TRY(gemm(s, true, false, dF2, FC, F1, FC, g->fc2_w, FC + A, FC, FC, (int)M));
-    T_TRY(gemm(s, true, false, dF2, FC, a4, R, g->fc2_w + FC, FC + A, FC, A, (int)M));
+    T_TRY(gemm_tn(dF2, FC, F1, FC, g->fc2_w, FC + A, FC, FC));
+    T_TRY(gemm_tn(dF2, FC, a4, R, g->fc2_w + FC, FC + A, FC, A));
     colsum(dF2, FC, FC, g->fc2_b);
     T_TRY(gemm(s, false, false, dF2, FC, w->fc2_w, FC + A, dF1, FC, M, FC, FC));
     if (d_aux_dev) T_TRY(gemm(s, false, false, dF2, FC, w->fc2_w + FC, FC + A, d_aux_dev + 3 * A, R, M, A, FC));
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(eb_f), dim3(256), 0, s, dF1, F1, (long)nF);
     // fc1 over cat[X3, a3]
-    T_TRY(gemm(s, true, false, dF1, FC, X3, H, g->fc1_w, H + A, FC, H, (int)M));
-    T_TRY(gemm(s, true, false, dF1, FC, a3, R, g->fc1_w + H, H + A, FC, A, (int)M));
+    T_TRY(gemm_tn(dF1, FC, X3, H, g->fc1_w, H + A, FC, H));
+    T_TRY(gemm_tn(dF1, FC, a3, R, g->fc1_w + H, H + A, FC, A));
     colsum(dF1, FC, FC, g->fc1_b);
     T_TRY(gemm(s, false, false, dF1, FC, w->fc1_w, H + A, dX3, H, M, H, FC));
     if (d_aux_dev) T_TRY(gemm(s, false, false, dF1, FC, w->fc1_w + H, H + A, d_aux_dev + 2 * A, R, M, A, FC));
@@ -552,15 +634,15 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
         hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (G + 31) / 32), dim3(256), 0, s, whh[i], q.WhhT, H, G);   // WhhT[j][k] = W_hh[k][j]
         return run_steps(st, &st->g_bwd[i], rebuild, s, [&](hipStream_t cs) {
             for (long t = L - 1; t >= 0; --t)
-                hipLaunchKernelGGL(gru_bwd_step_kernel, sgrid, dim3(256), lds_b, cs, dHext, q.WhhT, q.HP, q.R, q.Z, q.N, q.GHN, q.dGI, q.dGH, q.CD, B, L,
+                hipLaunchKernelGGL(bwd_k, sgrid, dim3(256), lds_b, cs, dHext, q.WhhT, q.HP, q.R, q.Z, q.N, q.GHN, q.dGI, q.dGH, q.CD, B, L,
                                    H, t);
         });
     };
     // rnn2: h2 enters x3 = x2 + h2, so dH2(ext) = dX3
     T_TRY(recur_bwd(1, dX3));
-    T_TRY(gemm(s, true, false, gr[1].dGI, G, X2, H, g->rnn2_w_ih, H + A, G, H, (int)M));
-    T_TRY(gemm(s, true, false, gr[1].dGI, G, a2, R, g->rnn2_w_ih + H, H + A, G, A, (int)M));
-    T_TRY(gemm(s, true, false, gr[1].dGH, G, gr[1].HP, H, g->rnn2_w_hh, H, G, H, (int)M));
+    T_TRY(gemm_tn(gr[1].dGI, G, X2, H, g->rnn2_w_ih, H + A, G, H));
+    T_TRY(gemm_tn(gr[1].dGI, G, a2, R, g->rnn2_w_ih + H, H + A, G, A));
+    T_TRY(gemm_tn(gr[1].dGH, G, gr[1].HP, H, g->rnn2_w_hh, H, G, H));
     colsum(gr[1].dGI, G, G, g->rnn2_b_ih);
     colsum(gr[1].dGH, G, G, g->rnn2_b_hh);
     T_TRY(hipMemcpyAsync(dX2, dX3, nH * sizeof(float), hipMemcpyDeviceToDevice, s));        // residual x3 = x2 + h2
@@ -568,16 +650,16 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     if (d_aux_dev) T_TRY(gemm(s, false, false, gr[1].dGI, G, w->rnn2_w_ih + H, H + A, d_aux_dev + A, R, M, A, G));
     // rnn1
     T_TRY(recur_bwd(0, dX2));
-    T_TRY(gemm(s, true, false, gr[0].dGI, G, XI, H, g->rnn1_w_ih, H, G, H, (int)M));
-    T_TRY(gemm(s, true, false, gr[0].dGH, G, gr[0].HP, H, g->rnn1_w_hh, H, G, H, (int)M));
+    T_TRY(gemm_tn(gr[0].dGI, G, XI, H, g->rnn1_w_ih, H, G, H));
+    T_TRY(gemm_tn(gr[0].dGH, G, gr[0].HP, H, g->rnn1_w_hh, H, G, H));
     colsum(gr[0].dGI, G, G, g->rnn1_b_ih);
     colsum(gr[0].dGH, G, G, g->rnn1_b_hh);
     T_TRY(hipMemcpyAsync(dXI, dX2, nH * sizeof(float), hipMemcpyDeviceToDevice, s));        // residual x2 = xI + h1
     T_TRY(gemm(s, false, false, gr[0].dGI, G, w->rnn1_w_ih, H, dXI, H, M, H, G, 1));
     // I over cat[x, mels, a1]
-    T_TRY(gemm(s, true, false, dXI, H, x_dev, 1, g->I_w, IN_I, H, 1, (int)M));
-    T_TRY(gemm(s, true, false, dXI, H, mels_up_dev, F, g->I_w + 1, IN_I, H, F, (int)M));
-    T_TRY(gemm(s, true, false, dXI, H, a1, R, g->I_w + 1 + F, IN_I, H, A, (int)M));
+    T_TRY(gemm_tn(dXI, H, x_dev, 1, g->I_w, IN_I, H, 1));
+    T_TRY(gemm_tn(dXI, H, mels_up_dev, F, g->I_w + 1, IN_I, H, F));
+    T_TRY(gemm_tn(dXI, H, a1, R, g->I_w + 1 + F, IN_I, H, A));
     colsum(dXI, H, H, g->I_b);
     if (d_mels_up_dev) T_TRY(gemm(s, false, false, dXI, H, w->I_w + 1, IN_I, d_mels_up_dev, F, M, F, H));
     if (d_aux_dev) T_TRY(gemm(s, false, false, dXI, H, w->I_w + 1 + F, IN_I, d_aux_dev, R, M, A, H));

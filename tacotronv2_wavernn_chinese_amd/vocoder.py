@@ -27,6 +27,7 @@ from typing import Optional, Union
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _cabi
 from .dsp import decode_mu_law, save_wav
@@ -139,6 +140,17 @@ class WaveRNN(nn.Module):
         """Force the next ``generate`` to repack the weights into the native handle."""
         self._native_key = None
 
+    def _native_handle(self) -> _cabi.NativeVocoder:
+        """The wrnn_handle for the current device WITHOUT (re)packing the inference weights: what ``wrnn_train_step`` needs
+        (dims, mode, workspace) -- the parameters change every optimizer step and are read where torch keeps them."""
+        dev = self._device_index()
+        if self._native is None or self._native.device != dev:
+            if self._native is not None:
+                self._native.close()
+            self._native = _cabi.NativeVocoder(device=dev, **self._ctor)
+            self._native_key = None
+        return self._native
+
     def native(self) -> _cabi.NativeVocoder:
         """The wrnn_handle for the current device, repacked if parameters changed."""
         dev = self._device_index()
@@ -178,6 +190,57 @@ class WaveRNN(nn.Module):
         res = self.generate_raw(mels_t, False, 11000, 550, x_forced=x_forced, x_init=xs[:, 0], want_logits=True,
                                 mels_padded=True, **kw)
         return res['logits'].permute(1, 0, 2).contiguous()
+
+    # ---------------------------------------------------------------- training
+    def upsample_torch(self, mels):
+        """``self.upsample(mels)`` of the reference (UpsampleNetwork.forward :82-89, MelResNet :42-48, ResBlock :21-28,
+        Stretch2d :57-61) on the framework's own ops, for TRAINING: BatchNorm follows ``self.training`` (batch statistics +
+        running-stat updates in train mode) and the result carries an autograd graph, so the upsample network's parameters
+        train through ``loss.backward()``.  mels (B, n_mels, T + 2*pad) -> (mels_up (B, L, n_mels), aux (B, L, res_out))."""
+        r = self.upsample.resnet
+        x = F.relu(r.batch_norm(r.conv_in(mels)))
+        for blk in r.layers:
+            res = x
+            x = F.relu(blk.batch_norm1(blk.conv1(x)))
+            x = blk.batch_norm2(blk.conv2(x))
+            x = x + res
+        aux = r.conv_out(x)                                                   # (B, res_out, T)
+        aux = aux.repeat_interleave(self.hop_length, dim=2)                   # Stretch2d(total_scale, 1) (:70,:84)
+        m = mels.unsqueeze(1)
+        for i, s in enumerate(self._ctor['upsample_factors']):
+            m = m.repeat_interleave(s, dim=3)                                 # Stretch2d(s, 1)
+            m = self.upsample.up_layers[2 * i + 1](m)
+        indent = self.pad * self.hop_length
+        m = m.squeeze(1)[:, :, indent:-indent]
+        return m.transpose(1, 2), aux.transpose(1, 2)
+
+    def _loop_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in _cabi.LOOP_PARAM_KEYS]
+
+    def training_loss(self, x, mels, y, return_logits=False):
+        """One training step's forward as the reference's loop body computes it (``wavernn_train.py:103-121``):
+        ``y_hat = model(x, mels)`` + ``F.cross_entropy`` (RAW) / ``discretized_mix_logistic_loss`` (MOL), as a 0-dim tensor WITH
+        an autograd graph: ``loss.backward()`` fills ``.grad`` of every parameter, after which ``clip_grad_norm_`` /
+        ``optimizer.step()`` work as in the reference.  The loop layers (I, rnn1, rnn2, fc1-3: 97 % of the FLOPs) run
+        forward AND backward in ``wrnn_train_step`` (csrc/train.hip: batched fp32 MFMA GEMMs over all (batch, step) pairs +
+        BPTT step kernels replayed from hipGraphs); the upsample network runs on the framework's ops (``upsample_torch``).
+        x (B, L) float inputs, mels (B, n_mels, T + 2*pad), y (B, L) int labels (RAW) / float targets (MOL), L = T * hop.
+        Increments ``step`` like ``forward`` (:139)."""
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('training_loss needs the model on the MI355X (no CPU path in this package)')
+        x = torch.as_tensor(x).to(device=dev, dtype=torch.float32).contiguous()
+        mels = torch.as_tensor(mels).to(device=dev, dtype=torch.float32)
+        y = torch.as_tensor(y).to(device=dev)
+        y = (y.to(torch.int32) if self.mode == 'RAW' else y.to(torch.float32)).contiguous()
+        T = mels.size(-1) - 2 * self.pad
+        if mels.dim() != 3 or T < 1 or tuple(x.shape) != (mels.size(0), T * self.hop_length) or tuple(y.shape) != tuple(x.shape):
+            raise ValueError(f'expected x, y (B, {max(T, 0) * self.hop_length}) for mels {tuple(mels.shape)}')
+        self.step += 1
+        mels_up, aux = self.upsample_torch(mels)
+        out = _LoopTrainFn.apply(self, x, y, return_logits, mels_up.contiguous(), aux.contiguous(), *self._loop_params())
+        return out if return_logits else out[0]
 
     # ---------------------------------------------------------------- generate
     def generate_raw(self, mels, batched, target, overlap, *, noise_mode=_cabi.NOISE_PHILOX, seed=0,
@@ -419,3 +482,32 @@ class WaveRNN(nn.Module):
         if print_out:
             print('Trainable Parameters: %.3fM' % n)
         return n
+
+
+class _LoopTrainFn(torch.autograd.Function):
+    """loss = L(loop layers(x, mels_up, aux; params)) with forward and backward in ``wrnn_train_step``."""
+
+    @staticmethod
+    def forward(ctx, model, x, y, want_logits, mels_up, aux, *params):
+        nat = model._native_handle()
+        dev = x.device
+        B, L = x.shape
+        grads = [torch.empty_like(p) for p in params]
+        d_m, d_a = torch.empty_like(mels_up), torch.empty_like(aux)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, L, model.n_classes), dtype=torch.float32, device=dev) if want_logits else None
+        ps = [p.detach().contiguous() for p in params]
+        with torch.cuda.device(dev):
+            nat.train_step([p.data_ptr() for p in ps], [g.data_ptr() for g in grads], x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(),
+                           y.data_ptr(), B, L, loss.data_ptr(), logits.data_ptr() if want_logits else 0, d_m.data_ptr(), d_a.data_ptr(),
+                           torch.cuda.current_stream(dev).cuda_stream)
+        ctx.save_for_backward(d_m, d_a, *grads)
+        if want_logits:
+            ctx.mark_non_differentiable(logits)
+            return loss, logits
+        return (loss,)
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        d_m, d_a, *grads = ctx.saved_tensors
+        return (None, None, None, None, d_m * g_loss, d_a * g_loss) + tuple(g * g_loss for g in grads)
