@@ -44,6 +44,9 @@ LONG_CASES = [
 FORWARD_CASES = [
     dict(name='fwd_raw_peaky_b2_t6', mode='RAW', bits=10, variant='peaky', B=2, T=6),
     dict(name='fwd_mol_default_b2_t6', mode='MOL', bits=9, variant='default', B=2, T=6),
+    # wider: 4 rows x 20 frames (5 500 steps per row: several frame changes per row, more rows than a row quad of the batch kernel)
+    dict(name='fwd_raw_peaky_b4_t20', mode='RAW', bits=10, variant='peaky', B=4, T=20, sub=97),
+    dict(name='fwd_mol_default_b4_t20', mode='MOL', bits=9, variant='default', B=4, T=20, sub=23),
 ]
 # One training iteration (`python -m oracle.make_golden train`): forward in train() mode (BatchNorm on batch statistics), loss,
 # loss.backward() -- the loss and, per parameter, the gradient's L2 norm + a strided sample of it (the full gradients are 17 MB)
@@ -114,11 +117,12 @@ def mint_forward():
             y[0, :7] = [-1.0, -0.9995, 0.9995, 1.0, 0.0, 0.5, -0.5]   # the edge branches of the discretised likelihood
             x = rng.uniform(-1.0, 1.0, size=(B, L)).astype(np.float32)
         out = rh.reference_forward(model, x, mels, y)
-        sub = slice(0, L, 23)
+        stride = c.get('sub', 23)
+        sub = slice(0, L, stride)
         import torch
         loss_sub = out['loss_of'](torch.from_numpy(np.ascontiguousarray(out['logits'][:, sub])), y[:, sub])
         fix = dict(mode=c['mode'], bits=c['bits'], variant=c['variant'], B=B, T=T, weight_seed=WEIGHT_SEED, mel_seed=MEL_SEED,
-                   xy_seed=NOISE_SEED, x=x, y=y, logits_sub=out['logits'][:, sub].astype(np.float32), sub_stride=23,
+                   xy_seed=NOISE_SEED, x=x, y=y, logits_sub=out['logits'][:, sub].astype(np.float32), sub_stride=stride,
                    loss=np.float64(out['loss']), loss_sub=np.float64(loss_sub))
         path = os.path.join(GOLDEN_DIR, c['name'] + '.npz')
         np.savez_compressed(path, **fix)

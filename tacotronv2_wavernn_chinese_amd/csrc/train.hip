@@ -206,11 +206,21 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 // ---- GRU recurrence, forward: one launch per time step ---------------------------------------------------------------------
 // nn.GRU, one layer (gate order r, z, n; get_gru_cell :273-279):  gi = GI[b, t] (input part incl. b_ih, precomputed),
 // gh = W_hh h_{t-1} + b_hh;  r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h = (1 - z) n + z h_{t-1}.
-// grid (H / 4, ceil(B / 32)), block 256: wave u = hidden unit j0 + u, lane = (K half kh, batch row b).
+// grid (H / 4, ceil(B / 32)), block 256.  A workgroup owns 4 hidden units (12 gate rows) for 32 batch rows:
+//   gh[32 x 12] = h_{t-1}[32 x H] . W^T[H x 12]   on v_mfma_f32_16x16x4f32 (two 16-row tiles x one 16-column tile, 4 columns idle),
+// K split over the 4 waves (the first version evaluated it with v_fma from LDS operands: LDS-read bound, 11.4 us per step; the MFMA
+// takes one b32 LDS read per operand and K step).  Operands staged through LDS with row pitch H + 4 floats (conflict-free b32
+// reads for "lane = row"), partial tiles of the 4 waves summed in wave order through LDS, then 128 threads = (row, unit) do the gates.
 #define GR_UW 4
 #define GR_HLD(H) ((H) + 4)
-// HT = rnn_dims at compile time (the reference's 512: every load loop unrolls, all loads of a phase are in flight at once --
-// measured 14 -> ~4 us per step against run-time trip counts, whose loop issues one L2 round trip per iteration); HT = 0: any H
+typedef float f4v __attribute__((ext_vector_type(4)));
+// XCD-aware workgroup -> tile map.  Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8) and every
+// XCD has its own L2.  A step kernel's workgroup writes 4 consecutive floats per output row: with tile = blockIdx the 8
+// workgroups that share a 128-byte line sit on 8 different XCDs and every line is written back in 8 partial pieces at the end of
+// the kernel; with this map the workgroups of one XCD own one contiguous range of hidden units, i.e. whole lines.
+__device__ __forceinline__ int xcd_tile(int bid, int nblk) { return (nblk & 7) ? bid : (bid & 7) * (nblk >> 3) + (bid >> 3); }
+// HT = rnn_dims at compile time (the reference's 512: every load loop unrolls, all loads of a phase are in flight at once;
+// with run-time trip counts the staging loop issues one L2 round trip per iteration: 14 us per step); HT = 0: any H % 16 == 0
 template <int HT>
 __global__ void __launch_bounds__(256) gru_fwd_step_kernel(const float *__restrict__ GI, const float *__restrict__ Whh, const float *__restrict__ bhh,
                                                            float *__restrict__ Hs /* (B, L, H) h_t */, float *__restrict__ HP /* (B, L, H) h_{t-1} */,
@@ -218,53 +228,102 @@ __global__ void __launch_bounds__(256) gru_fwd_step_kernel(const float *__restri
                                                            float *__restrict__ GHN, int B, long L, int Hrt, long t) {
     const int H = HT ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *hs = sm;                                    // [32][H + 4]
-    float *ws = sm + 32 * GR_HLD(H);                   // [3 gates][4 units][H]
-    const int tid = threadIdx.x;
-    const int j0 = blockIdx.x * GR_UW, b0 = blockIdx.y * 32;
     const int hld = GR_HLD(H);
+    float *hs = sm;                                    // [32][H + 4]   h_{t-1}
+    float *ws = sm + 32 * hld;                         // [12][H + 4]   W_hh rows g * 4 + u
+    float *ps = ws + 12 * hld;                         // [4 waves][32 rows][16]  partial gh tiles
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int j0 = xcd_tile(blockIdx.x, gridDim.x) * GR_UW, b0 = blockIdx.y * 32;
+    // the (row, unit) threads of the gate phase request their inputs first: that round trip (every kernel starts with a cold L2:
+    // the previous step's results were written back at its end) then runs under the staging instead of behind the MFMAs
+    const int gb = tid & 31, gu = (tid >> 5) & 3;
+    const bool gate_thread = tid < 128 && b0 + gb < B;
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, bh_r = 0.f, bh_z = 0.f, bh_n = 0.f;
+    if (gate_thread) {
+        const float *gi = GI + ((size_t)(b0 + gb) * L + t) * 3 * H + j0 + gu;
+        gi_r = gi[0]; gi_z = gi[H]; gi_n = gi[2 * H];
+        bh_r = bhh[j0 + gu]; bh_z = bhh[H + j0 + gu]; bh_n = bhh[2 * H + j0 + gu];
+    }
     {
-        // h_{t-1} rows and the 12 weight rows as float4, one wave per row, lanes over the row (coalesced, no index division)
-        const int wv = tid >> 6, ln = tid & 63, h4 = H / 4;
+        // staging with compile-time trip counts (8 rows and 3 weight rows per wave; `for (b = wv; b < 32; b += 4)` is not unrolled --
+        // wv is a run-time value -- and then every iteration waits for its own L2 round trip: 11 of them were the kernel's 9 us)
+        const int h4 = H / 4;
+        if (HT) {
+            constexpr int C4 = HT ? HT / 256 : 1;      // float4 per lane and row
+            float4 th[8][C4], tw[3][C4];
 #pragma unroll
-        for (int b = wv; b < 32; b += 4) {
-            const float4 *src = (const float4 *)(HP + ((size_t)(b0 + b) * L + t) * H);
-            float4 *dst = (float4 *)(hs + b * hld);
-            const bool ok = b0 + b < B;
+            for (int i = 0; i < 8; ++i) {
+                const int b = wv + 4 * i;
+                const float4 *src = (const float4 *)(HP + ((size_t)(b0 + b) * L + t) * H);
+                const bool ok = b0 + b < B;
 #pragma unroll
-            for (int c = ln; c < h4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+                for (int c = 0; c < C4; ++c) th[i][c] = ok ? src[ln + 64 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int row = wv; row < 3 * GR_UW; row += 4) {   // row = g * 4 + u
-            const float4 *src = (const float4 *)(Whh + ((size_t)(row >> 2) * H + j0 + (row & 3)) * H);
-            float4 *dst = (float4 *)(ws + row * H);
+            for (int i = 0; i < 3; ++i) {
+                const int row = wv + 4 * i;               // row = g * 4 + u
+                const float4 *src = (const float4 *)(Whh + ((size_t)(row >> 2) * H + j0 + (row & 3)) * H);
 #pragma unroll
-            for (int c = ln; c < h4; c += 64) dst[c] = src[c];
+                for (int c = 0; c < C4; ++c) tw[i][c] = src[ln + 64 * c];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int c = 0; c < C4; ++c) ((float4 *)(hs + (wv + 4 * i) * hld))[ln + 64 * c] = th[i][c];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < C4; ++c) ((float4 *)(ws + (wv + 4 * i) * hld))[ln + 64 * c] = tw[i][c];
+        } else {
+            for (int b = wv; b < 32; b += 4) {
+                const float4 *src = (const float4 *)(HP + ((size_t)(b0 + b) * L + t) * H);
+                float4 *dst = (float4 *)(hs + b * hld);
+                const bool ok = b0 + b < B;
+                for (int c = ln; c < h4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            for (int row = wv; row < 3 * GR_UW; row += 4) {
+                const float4 *src = (const float4 *)(Whh + ((size_t)(row >> 2) * H + j0 + (row & 3)) * H);
+                float4 *dst = (float4 *)(ws + row * hld);
+                for (int c = ln; c < h4; c += 64) dst[c] = src[c];
+            }
         }
     }
     __syncthreads();
-    const int u = tid >> 6, kh = (tid >> 5) & 1, b = tid & 31;
-    const int kq = H / 2;
-    const float4 *hp = (const float4 *)(hs + b * hld + kh * kq);
-    const float4 *wr = (const float4 *)(ws + (0 * GR_UW + u) * H + kh * kq);
-    const float4 *wz = (const float4 *)(ws + (1 * GR_UW + u) * H + kh * kq);
-    const float4 *wn = (const float4 *)(ws + (2 * GR_UW + u) * H + kh * kq);
-    float ar = 0.f, az = 0.f, an = 0.f;
+    {
+        // wave wv: k in [wv * H/4, (wv + 1) * H/4).  A lane (m = ln % 16, kk = ln / 16) = h[tile * 16 + m][k + kk];
+        // B lane (kk, n = ln % 16) = W[n][k + kk] (n < 12, else 0);  D lane: rows 4 * (ln / 16) + i, column ln % 16
+        const int m = ln & 15, kk = ln >> 4, kq = H / 4;
+        const float *a0p = hs + m * hld + wv * kq + kk, *a1p = a0p + 16 * hld;
+        const float *bp = ws + (m < 12 ? m : 0) * hld + wv * kq + kk;
+        const bool bz = m >= 12;
+        f4v d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int k = 0; k < kq / 4; ++k) {
-        const float4 hv = hp[k], a = wr[k], c = wz[k], d = wn[k];
-        ar = fmaf(a.w, hv.w, fmaf(a.z, hv.z, fmaf(a.y, hv.y, fmaf(a.x, hv.x, ar))));
-        az = fmaf(c.w, hv.w, fmaf(c.z, hv.z, fmaf(c.y, hv.y, fmaf(c.x, hv.x, az))));
-        an = fmaf(d.w, hv.w, fmaf(d.z, hv.z, fmaf(d.y, hv.y, fmaf(d.x, hv.x, an))));
+        for (int k = 0; k < kq; k += 4) {
+            const float bv = bz ? 0.0f : bp[k];
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[k], bv, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[k], bv, d1, 0, 0, 0);
+        }
+        float *pw = ps + wv * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pw[(4 * kk + i) * 16 + m] = d0[i];
+            pw[(16 + 4 * kk + i) * 16 + m] = d1[i];
+        }
     }
-    ar += __shfl_xor(ar, 32, 64); az += __shfl_xor(az, 32, 64); an += __shfl_xor(an, 32, 64);
-    if (kh == 0 && b0 + b < B) {
+    __syncthreads();
+    if (gate_thread) {
+        const int b = gb, u = gu;
+        float gh[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int o = b * 16 + g * 4 + u;
+            gh[g] = (ps[o] + ps[512 + o]) + (ps[1024 + o] + ps[1536 + o]);
+        }
         const int j = j0 + u;
         const size_t row = (size_t)(b0 + b) * L + t;
-        const float *gi = GI + row * 3 * H;
-        const float ghr = ar + bhh[j], ghz = az + bhh[H + j], ghn = an + bhh[2 * H + j];
-        const float r = sigm(gi[j] + ghr), z = sigm(gi[H + j] + ghz);
-        const float n = tanhf(gi[2 * H + j] + r * ghn);
+        const float ghr = gh[0] + bh_r, ghz = gh[1] + bh_z, ghn = gh[2] + bh_n;
+        const float r = sigm(gi_r + ghr), z = sigm(gi_z + ghz);
+        const float n = tanhf(gi_n + r * ghn);
         const float hprev = hs[b * hld + j];
         const float h = (1.0f - z) * n + z * hprev;
         Hs[row * H + j] = h;
@@ -277,7 +336,9 @@ __global__ void __launch_bounds__(256) gru_fwd_step_kernel(const float *__restri
 // dH_t = dHext[b, t] (from the layers above: x_out = x_in + h) + carry_t,   carry_t = dH_{t+1} z_{t+1} + dGH_{t+1} . W_hh
 // dn = dH (1 - z), dz = dH (h_{t-1} - n), dpn = dn (1 - n^2), dr = dpn gh_n, dpr = dr r (1 - r), dpz = dz z (1 - z)
 // dGI_t = [dpr, dpz, dpn]   dGH_t = [dpr, dpz, dpn r]   CD_t = dH z      (dGI / dGH feed the batched weight / input GEMMs)
-// WhhT = W_hh transposed, [H][3H]: the workgroup's 4 units are 4 contiguous rows.  Same grid / thread map as the forward step.
+// WhhT = W_hh transposed, [H][3H]: the workgroup's 4 units are 4 contiguous rows.  Same grid as the forward step;
+// carry[32 x 4] = dGH_{t+1}[32 x 3H] . WhhT^T[3H x 4] on the same MFMA shape (12 of 16 columns idle: the chip has more CUs than
+// this launch has workgroups, so the idle columns cost no time), dGH staged in chunks of GB_KC columns.
 #define GB_KC 768
 template <int HT>
 __global__ void __launch_bounds__(256) gru_bwd_step_kernel(const float *__restrict__ dHext, const float *__restrict__ WhhT,
@@ -287,54 +348,112 @@ __global__ void __launch_bounds__(256) gru_bwd_step_kernel(const float *__restri
                                                            long t) {
     const int H = HT ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int G = 3 * H, gld = GB_KC + 4, wld = G + 4;
     float *gs = sm;                                    // [32][GB_KC + 4] chunk of dGH_{t+1}
-    float *ws = sm + 32 * (GB_KC + 4);                 // [4 units][3H]
-    const int tid = threadIdx.x;
-    const int j0 = blockIdx.x * GR_UW, b0 = blockIdx.y * 32;
-    const int u = tid >> 6, kh = (tid >> 5) & 1, b = tid & 31;
-    const int G = 3 * H;
-    float carry = 0.0f;
-    if (t + 1 < L) {
-        const int wv = tid >> 6, ln = tid & 63;
+    float *ws = sm + 32 * gld;                         // [4 units][3H + 4]
+    float *ps = ws + GR_UW * wld;                      // [4 waves][32 rows][4 units]
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int j0 = xcd_tile(blockIdx.x, gridDim.x) * GR_UW, b0 = blockIdx.y * 32;
+    const bool have = t + 1 < L;
+    // inputs of the gate-derivative phase requested first (see gru_fwd_step_kernel)
+    const int gb = tid & 31, gu = (tid >> 5) & 3;
+    const bool gate_thread = tid < 128 && b0 + gb < B;
+    float e_dh = 0.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_ghn = 0.f, e_hp = 0.f, e_cd = 0.f;
+    if (gate_thread) {
+        const size_t o = ((size_t)(b0 + gb) * L + t) * H + j0 + gu;
+        e_dh = dHext[o]; e_r = Rs[o]; e_z = Zs[o]; e_n = Ns[o]; e_ghn = GHN[o]; e_hp = HP[o];
+        if (have) e_cd = CD[(size_t)(b0 + gb) * H + j0 + gu];
+    }
+    if (have) {
         {
             const float4 *src = (const float4 *)(WhhT + (size_t)(j0 + wv) * G);   // wave u stages its own unit's row
-            float4 *dst = (float4 *)(ws + wv * G);
+            float4 *dst = (float4 *)(ws + wv * wld);
+            if (HT) {
+                constexpr int W4 = HT ? 3 * HT / 256 : 1;
+                float4 tw[W4];
 #pragma unroll
-            for (int c = ln; c < G / 4; c += 64) dst[c] = src[c];
-        }
-        float acc = 0.0f;
+                for (int c = 0; c < W4; ++c) tw[c] = src[ln + 64 * c];
 #pragma unroll
-        for (int c0 = 0; c0 < G; c0 += GB_KC) {
-            const int cw = G - c0 < GB_KC ? G - c0 : GB_KC;
-            __syncthreads();
-#pragma unroll
-            for (int bb = wv; bb < 32; bb += 4) {
-                const float4 *src = (const float4 *)(dGH + ((size_t)(b0 + bb) * L + t + 1) * G + c0);
-                float4 *dst = (float4 *)(gs + bb * (GB_KC + 4));
-                const bool ok = b0 + bb < B;
-#pragma unroll
-                for (int c = ln; c < cw / 4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = 0; c < W4; ++c) dst[ln + 64 * c] = tw[c];
+            } else {
+                for (int c = ln; c < G / 4; c += 64) dst[c] = src[c];
             }
-            __syncthreads();
-            const int half = cw / 2;                   // cw is a multiple of 8 for the supported dims (3H, H % 8 == 0)
-            const float4 *gp = (const float4 *)(gs + b * (GB_KC + 4) + kh * half);
-            const float4 *wp = (const float4 *)(ws + u * G + c0 + kh * half);
+        }
+        const int m = ln & 15, kk = ln >> 4;
+        const bool bz = m >= GR_UW;
+        f4v d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        auto mfma_chunk = [&](int c0, int cw) {
+            const int kq = cw / 4;                     // this wave's share of the chunk (cw % 16 == 0)
+            const float *a0p = gs + m * gld + wv * kq + kk, *a1p = a0p + 16 * gld;
+            const float *bp = ws + (bz ? 0 : m) * wld + c0 + wv * kq + kk;
 #pragma unroll 8
-            for (int k = 0; k < half / 4; ++k) {
-                const float4 gv = gp[k], wv = wp[k];
-                acc = fmaf(wv.w, gv.w, fmaf(wv.z, gv.z, fmaf(wv.y, gv.y, fmaf(wv.x, gv.x, acc))));
+            for (int k = 0; k < kq; k += 4) {
+                const float bv = bz ? 0.0f : bp[k];
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[k], bv, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[k], bv, d1, 0, 0, 0);
+            }
+        };
+        if (HT) {
+            // compile-time trip counts, and BOTH chunks requested before the first LDS store: one memory round trip for the whole
+            // dGH_{t+1} block (a `for (bb = wv; ...)` loop is not unrolled -- wv is a run-time value -- and waits per iteration)
+            constexpr int NCH = HT ? 3 * HT / GB_KC : 1, K4 = GB_KC / 256;
+            static_assert(HT == 0 || (3 * HT) % GB_KC == 0, "3H must be a multiple of the chunk");
+            float4 tg[NCH][8][K4];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int bb = wv + 4 * i;
+                    const float4 *src = (const float4 *)(dGH + ((size_t)(b0 + bb) * L + t + 1) * G + ch * GB_KC);
+                    const bool ok = b0 + bb < B;
+#pragma unroll
+                    for (int c = 0; c < K4; ++c) tg[ch][i][c] = ok ? src[ln + 64 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int c = 0; c < K4; ++c) ((float4 *)(gs + (wv + 4 * i) * gld))[ln + 64 * c] = tg[ch][i][c];
+                __syncthreads();
+                mfma_chunk(ch * GB_KC, GB_KC);
+            }
+        } else {
+            for (int c0 = 0; c0 < G; c0 += GB_KC) {
+                const int cw = G - c0 < GB_KC ? G - c0 : GB_KC;
+                __syncthreads();
+                for (int bb = wv; bb < 32; bb += 4) {
+                    const float4 *src = (const float4 *)(dGH + ((size_t)(b0 + bb) * L + t + 1) * G + c0);
+                    float4 *dst = (float4 *)(gs + bb * gld);
+                    const bool ok = b0 + bb < B;
+                    for (int c = ln; c < cw / 4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                __syncthreads();
+                mfma_chunk(c0, cw);
             }
         }
-        acc += __shfl_xor(acc, 32, 64);
-        carry = acc;
+        if (m < GR_UW) {
+            float *pw = ps + wv * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pw[(4 * kk + i) * 4 + m] = d0[i];
+                pw[(16 + 4 * kk + i) * 4 + m] = d1[i];
+            }
+        }
     }
-    if (kh == 0 && b0 + b < B) {
+    __syncthreads();
+    if (gate_thread) {
+        const int b = gb, u = gu;
         const int j = j0 + u;
         const size_t row = (size_t)(b0 + b) * L + t;
-        if (t + 1 < L) carry += CD[(size_t)(b0 + b) * H + j];
-        const float dH = dHext[row * H + j] + carry;
-        const float r = Rs[row * H + j], z = Zs[row * H + j], n = Ns[row * H + j], ghn = GHN[row * H + j];
-        const float hprev = HP[row * H + j];
+        float carry = 0.0f;
+        if (have) {
+            const int o = b * 4 + u;
+            carry = ((ps[o] + ps[128 + o]) + (ps[256 + o] + ps[384 + o])) + e_cd;
+        }
+        const float dH = e_dh + carry;
+        const float r = e_r, z = e_z, n = e_n, ghn = e_ghn, hprev = e_hp;
         const float dn = dH * (1.0f - z), dz = dH * (hprev - n);
         const float dpn = dn * (1.0f - n * n);
         const float dpr = (dpn * ghn) * r * (1.0f - r), dpz = dz * z * (1.0f - z);
@@ -498,8 +617,9 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     if (g && (!y_dev || !loss_out_dev)) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: gradients need targets and a loss output");
     const WrnnDims &d = h->d;
     const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, NC = d.NC;
-    if (H % 8 != 0 || H > 2048 || FC < 1) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: rnn_dims must be a multiple of 8 (<= 2048)");
-    if ((size_t)(32 * GR_HLD(H) + 3 * GR_UW * H) * 4 > 160u * 1024u || (size_t)(32 * (GB_KC + 4) + GR_UW * 3 * H) * 4 > 160u * 1024u)
+    if (H % 16 != 0 || FC < 1) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: rnn_dims must be a multiple of 16");
+    const size_t lds_f = (size_t)(44 * GR_HLD(H) + 4 * 512) * sizeof(float), lds_b = (size_t)(32 * (GB_KC + 4) + GR_UW * (3 * H + 4) + 4 * 128) * sizeof(float);
+    if (lds_f > 160u * 1024u || lds_b > 160u * 1024u)
         return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: rnn_dims too large for the step kernels' LDS tiles");
     T_TRY(hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
@@ -544,7 +664,6 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     st->B = B; st->L = L;
     for (int i = 0; i < 2; ++i) { st->w_hh[i] = whh[i]; st->b_hh[i] = bhh[i]; }
     (void)hipGetLastError();
-    const size_t lds_f = (size_t)(32 * GR_HLD(H) + 3 * GR_UW * H) * sizeof(float), lds_b = (size_t)(32 * (GB_KC + 4) + GR_UW * G) * sizeof(float);
     auto *fwd_k = H == 512 ? gru_fwd_step_kernel<512> : gru_fwd_step_kernel<0>;
     auto *bwd_k = H == 512 ? gru_bwd_step_kernel<512> : gru_bwd_step_kernel<0>;
     T_TRY(hipFuncSetAttribute((const void *)fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));

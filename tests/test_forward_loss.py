@@ -11,7 +11,7 @@ from oracle import oracle as orc
 from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_mels, make_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['fwd_raw_peaky_b2_t6', 'fwd_mol_default_b2_t6']
+CASES = ['fwd_raw_peaky_b2_t6', 'fwd_mol_default_b2_t6', 'fwd_raw_peaky_b4_t20', 'fwd_mol_default_b4_t20']
 
 
 def _load(name):
