@@ -28,7 +28,8 @@ Extra objects on the JSON line:
                    8d) or FLOPs (8 668 160 per sample RAW) x steps per launch / the loop kernel's average launch duration
                    (HIP events recorded by the library on the launch stream), against the bound SURVEY 8d names for the
                    batch size: HBM for B=1 and MOL B=32 (`peak` = the 8 TB/s of the data sheet, `peak_measured` = a
-                   device-to-device copy timed in this run, read + write bytes), the fp32 matrix/vector peak 157.3 TFLOP/s
+                   read-only stream over 1 GiB timed in this run, `peak_measured_copy` = a device-to-device copy, read + write
+                   bytes), the fp32 matrix/vector peak 157.3 TFLOP/s
                    for B=64.  `traffic` = measured HBM bytes per launch from the PMC passes under profiles/ (a static
                    number from that profile, not from this run: `traffic_source` says which file).  For B=1 the weights are
                    register/LDS resident and HBM is idle: the bound that actually binds is the exchange latency,
@@ -69,10 +70,10 @@ CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
            3: dict(mode='RAW', bits=10, batch=64, name='configs[3]')}
 # HBM bytes of the loop kernel per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md + WRITE_SIZE), keyed by (config, kernel); absent = not measured.  STATIC numbers.
-TRAFFIC_SOURCE = 'profiles/r02_rocprofv3_summary.txt (static: PMC passes of round 2 on the same kernels, not this run)'
-TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_462_885 + 1_913_781,            # fetch_c1 + write_c1, per segment launch
-                            (2, 4): 1_795_037_056 + 60_130_080,        # fetch_c2 + write_c2: the one launch of 64 x 110 275 samples
-                            (3, 4): 1_795_037_056 + 60_130_080}
+TRAFFIC_SOURCE = 'profiles/r03_rocprofv3_summary.txt (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round 3 on the shipped kernels, not this run)'
+TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_463_506 + 1_913_781,            # fetch_c1 + write_c1, per segment launch
+                            (2, 4): 1_795_034_496 + 59_779_232,        # fetch_c2 + write_c2: the one launch of 64 x 110 275 samples
+                            (3, 4): 1_795_034_496 + 59_779_232}
 # What bounds the B=1 latency kernel: 4 dependent all-gathers among the 32 workgroups of one XCD per step.
 # bench_micro/handoff.hip measures one such round (512 granules published, polled with sc1 loads, written to LDS, 2
 # barriers, NO compute between rounds): profiles/r03_handoff_microbench.txt.
@@ -124,24 +125,27 @@ def cpu_reference() -> dict | None:
     return out
 
 
-def measure_copy_peak(dev, nbytes: int = 1 << 30, reps: int = 8) -> float | None:
-    """Device-to-device copy of `nbytes` timed with HIP events on the current stream: (read + write) bytes / s.  SURVEY 8d:
-    "replace nominal with a measured device-copy peak on the box".  bench_micro/devcopy.hip is the hand-written version."""
+def measure_hbm_peaks(dev, nbytes: int = 1 << 30, reps: int = 8) -> dict | None:
+    """Device-memory bandwidth of THIS box, timed with HIP events on the current stream ("replace nominal with a measured
+    device-copy peak on the box"): `copy` = device-to-device copy, read + write bytes / s; `read` = a read-only stream (a sum
+    reduction over the buffer).  bench_micro/devcopy.hip is the hand-written version (profiles/r03_devcopy.txt)."""
     import torch
     try:
         src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
         dst = torch.empty_like(src)
-        dst.copy_(src)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / reps
+        out = {}
+        for name, fn, factor in (('copy', lambda: dst.copy_(src), 2.0), ('read', lambda: src.sum(), 1.0)):
+            fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            out[name] = factor * nbytes / (e0.elapsed_time(e1) / reps * 1e-3)
         del src, dst
-        return 2.0 * nbytes / (ms * 1e-3)
+        return out
     except Exception:   # the peak is an annotation: never sink the bench line for it
         return None
 
@@ -159,7 +163,7 @@ def self_launch(args) -> int:
 
 
 def run_config(cfg_id: int, *, world: int, rank: int, dev, dry: bool, steps: int, warmup: int, frames: int, batch: int,
-               kernel_name: str, copy_peak: float | None, dump: str | None = None, phase_profile: bool = False) -> dict | None:
+               kernel_name: str, copy_peak: dict | None, dump: str | None = None, phase_profile: bool = False) -> dict | None:
     """Time `steps` passes of config `cfg_id` (after `warmup` untimed ones) and return the fields of its JSON line (rank 0;
     None elsewhere)."""
     import torch
@@ -274,12 +278,13 @@ def run_config(cfg_id: int, *, world: int, rank: int, dev, dry: bool, steps: int
     else:
         roof = {'bound': 'hbm', 'achieved': round(rate * bytes_per_sample / 1e9, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': round(rate / bw_bound, 4)}
-        if copy_peak:
-            roof['peak_measured'] = round(copy_peak / 1e9, 1)
-            roof['frac_of_measured'] = round(rate * bytes_per_sample / copy_peak, 4)
+        if copy_peak:   # {'copy': ..., 'read': ...} B/s measured in this run; the algorithm's traffic is reads, so frac uses `read`
+            roof['peak_measured'] = round(copy_peak['read'] / 1e9, 1)
+            roof['peak_measured_copy'] = round(copy_peak['copy'] / 1e9, 1)
+            roof['frac_of_measured'] = round(rate * bytes_per_sample / copy_peak['read'], 4)
         roof_note = (f'achieved = algorithmic bytes ({bytes_per_sample:.0f} B/sample at B={rows}: weights once per step for the batch + 836 B) '
                      f'x steps per launch / average loop-kernel launch duration (HIP events around the {launches} launch(es) of one call); '
-                     'peak = data-sheet HBM bandwidth, peak_measured = device-to-device copy (read + write) timed in this run.  NOTIONAL for '
+                     'peak = data-sheet HBM bandwidth, peak_measured = read-only stream / peak_measured_copy = device copy (read + write) timed in this run.  NOTIONAL for '
                      'this kernel: the weights are register/LDS resident and never leave the chip (traffic: measured HBM bytes per launch)')
     roof['traffic'] = TRAFFIC_BYTES_PER_LAUNCH.get((cfg_id, kernel_ran)) if T == T_FRAMES else None
     roof['traffic_source'] = TRAFFIC_SOURCE if roof['traffic'] is not None else None
@@ -379,7 +384,7 @@ def main() -> int:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             dist.init_process_group('nccl', device_id=dev)
 
-    copy_peak = None if dry or rank != 0 else measure_copy_peak(dev)
+    copy_peak = None if dry or rank != 0 else measure_hbm_peaks(dev)
     out = run_config(args.config, world=world, rank=rank, dev=dev, dry=dry, steps=args.steps, warmup=args.warmup, frames=args.frames,
                      batch=args.batch, kernel_name=args.kernel, copy_peak=copy_peak, dump=args.dump, phase_profile=args.phase_profile)
     default_run = (args.config == 1 and world == 1 and not dry and not args.no_extra_configs and args.frames == T_FRAMES

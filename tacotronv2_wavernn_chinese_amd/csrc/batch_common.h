@@ -104,7 +104,9 @@ struct Lay {
     static constexpr int L_H1 = L_Q + VEC;         // h1', later fc1 outputs        (h2' = x3 - x2 is formed on the fly)
     static constexpr int L_XN = L_H1 + VEC;        // [16] x_{t-1} of every batch row
     static constexpr int L_MISC = L_XN + 16;       // [16]
-    static constexpr int L_TOTAL = L_MISC + 16;
+    static constexpr int L_PROF = L_MISC + 16;     // [4 waves][24] phase-cycle accumulators of the instrumented build (in LDS, not in
+                                                   // registers: the kernel has none to spare)
+    static constexpr int L_TOTAL = L_PROF + 96;
     static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
     // mailbox regions per team (granules); every region is double-buffered by step parity
     static constexpr unsigned RG = (unsigned)VEC;
@@ -248,13 +250,13 @@ __device__ __forceinline__ void mfma_single(const float *w, lds_cf4p xv, f4 (&su
 
 // phase-cycle instrumentation (WRNN_TEAM_PROF=1): the scheduling barriers keep the (side-effect free) MFMAs and VALU work of a
 // phase on its own side of the time stamp
-#define PB(i)                                                    \
-    do {                                                         \
-        if (PROF) {                                              \
-            __builtin_amdgcn_sched_barrier(0);                   \
-            const u64 now_ = __builtin_readcyclecounter();       \
-            __builtin_amdgcn_sched_barrier(0);                   \
-            prof_acc[i] += now_ - prof_last;                     \
-            prof_last = now_;                                    \
-        }                                                        \
+#define PB(i)                                                                  \
+    do {                                                                       \
+        if (PROF) {                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                 \
+            const unsigned now_ = (unsigned)__builtin_readcyclecounter();      \
+            __builtin_amdgcn_sched_barrier(0);                                 \
+            if (lane == 0) prof_lds[wl * 24 + (i)] += now_ - prof_last;        \
+            prof_last = now_;                                                  \
+        }                                                                      \
     } while (0)

@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
 
     bool dead = false;
     unsigned epoch = 0;
-    u64 prof_acc[WRNN_PROF_SLOTS] = {0};
-    u64 prof_last = 0;
+    unsigned *prof_lds = (unsigned *)(lds + L::L_PROF);   // 32-bit: a phase accumulates < 2^32 cycles per launch (3 000 x 110 275 = 3.3e8)
+    unsigned prof_last = 0;
 
     // schedule: batch b = slots [b * rpb, (b + 1) * rpb) of a.order; the batches are dealt to the teams round-robin, or in snake
     // order on a ragged batch (a.order is longest-first, so batches hold rows of similar length and the teams' sums even out)
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
         for (int64_t t = 0; t < bsteps; ++t) {
             ++epoch;
             const unsigned par = epoch & 1u;
-            if (PROF) prof_last = __builtin_readcyclecounter();
+            if (PROF) prof_last = (unsigned)__builtin_readcyclecounter();
 
             // ================= window 1: phase A | publish x2, h1' | gather both =================
             {
@@ -274,8 +274,17 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     st_granule(mail, L::G_H1 + par * L::RG + mb_own, epoch, __float_as_uint(h1));
                 }
                 frame_consts();   // constants of this step's frame (needed from phase B on)
+                // conditioning of the next step, behind the publish: the wave would otherwise only wait for the x2 exchange here
+                // (round 3: it sat at the start of window 5, where nothing is in flight: 740 serial cycles; B = 64 6 273 -> 6 634
+                // ksamples/s, MOL B = 32 5 008 -> 5 142, A/B in one session).  cond_combine() uses what was requested a step ago --
+                // loads OLDER than the granule stores above, so its wait does not include the stores' acknowledgement; the
+                // loads of cond_fetch(t + 2) land during the rest of the step.
+                if (t + 1 < bsteps) {
+                    cond_combine();
+                    if (t + 2 < bsteps) cond_fetch(t + 2);
+                }
             }
-            PB(0);   // phase A + publish
+            PB(0);   // phase A + publish + conditioning of the next step
             {
                 if (NQ == 1) {
                     // R = 4: both vectors in one round trip (2 x 4 loads in flight)
@@ -297,6 +306,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     PB(1);   // x2 arrived
 #pragma unroll
                     for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    // (requesting h1' -- needed by W_hh1 only -- behind phase B's MFMAs instead, with one more barrier: +0.1 %, not kept)
                     const unsigned offs2[1] = {(L::G_H1 + par * L::RG) * 8u};
                     gather_vecs<NM, 1>(mrs, gvoff, offs2, epoch, gx, dead, a.err, 22u);
 #pragma unroll
@@ -444,7 +454,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             {
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_F2 + par * L::RG) * 8u};
-                gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 25u);
+                gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 25u);   // (requesting the slices before the noise: 3 % slower,
+                                                                                     //  the early look comes back stale and takes the slow path)
 #pragma unroll
                 for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
             }
@@ -452,14 +463,8 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             __syncthreads();   // B4
             PB(19);
 
-            // ================= window 5: conditioning of the next step | phase E (fc3 :223 + sampler :225-237) | race =================
-            // (the record loads are issued here, a whole window after the last publish: a wait on them directly behind a
-            // granule store also waits for that store's acknowledgement -- stores count in vmcnt on gfx9 -- measured 2 281 cycles)
-            if (t + 1 < bsteps) {
-                cond_combine();                            // step t + 1 from what was requested a step ago
-                if (t + 2 < bsteps) cond_fetch(t + 2);     // lands during the next step
-            }
-            PB(17);  // conditioning of the next step
+            // ================= window 5: phase E (fc3 :223 + sampler :225-237) | race =================
+            PB(17);
             {
                 float lg0 = 0.f, lg1 = 0.f;
                 if (wg_has_fc3) {
@@ -642,7 +647,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
         __syncthreads();
     }
     if (PROF && a.prof && lane == 0 && g == 0 && team == 0) {
-        for (int i = 0; i < WRNN_PROF_SLOTS; ++i) a.prof[wl * WRNN_PROF_SLOTS + i] += prof_acc[i];
+        for (int i = 0; i < 24; ++i) a.prof[wl * WRNN_PROF_SLOTS + i] += prof_lds[wl * 24 + i];
     }
 }
 

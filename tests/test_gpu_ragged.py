@@ -137,3 +137,39 @@ def test_two_handles_share_a_gpu_without_timeouts():
     assert not errs, errs
     np.testing.assert_array_equal(out['a'], solo1)
     np.testing.assert_array_equal(out['b'], solo2)
+
+
+@pytest.mark.parametrize('mode,kernel,B', [('RAW', 'team2', 3), ('RAW', 'batch', 12), ('RAW', 'batch', 40), ('MOL', 'batch', 12)])
+def test_phase_profile_runs_the_instrumented_kernels_with_the_same_results(mode, kernel, B):
+    """wrnn_phase_profile / wrnn_phase_cycles (ABI 4; ABI 3 read an environment variable): the instrumented instantiations of the
+    team kernels ship in the library, so they are tested like everything else -- same labels / samples as the plain kernel,
+    plausible cycle counts (the instrumented RAW batch kernel used to fault: its 24 accumulators per wave now live in LDS)."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_mels, make_state_dict
+    from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+    bits = 10 if mode == 'RAW' else 9
+    sd = make_state_dict(0, mode=mode, variant='peaky' if mode == 'RAW' else 'default', bits=bits)
+    dims = dict(DEFAULT_DIMS)
+    dims['bits'] = bits
+    m = WaveRNN(**dims, mode=mode)
+    m.verbose = False
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m.to('cuda:0')
+    m.kernel = _cabi.KERNEL_TEAM2 if kernel == 'team2' else _cabi.KERNEL_BATCH
+    mels = make_mels(3, B, 6)
+    nat = m.native()
+    plain = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=9)
+    with pytest.raises(_cabi.WrnnError):
+        nat.phase_cycles()                                   # nothing instrumented ran yet
+    nat.phase_profile(True)
+    prof = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=9)
+    cyc = nat.phase_cycles()
+    nat.phase_profile(False)
+    np.testing.assert_array_equal(prof['labels'].cpu().numpy(), plain['labels'].cpu().numpy())
+    np.testing.assert_array_equal(prof['samples'].cpu().numpy(), plain['samples'].cpu().numpy())
+    assert cyc.shape == (8, 32)
+    if not (mode == 'MOL' and kernel == 'team2'):            # the latency kernel's instrumented build exists for RAW only
+        total = cyc[0].sum()
+        assert 3000 < total < 200000, total                  # cycles per step of wave 0: a few us at ~2.4 GHz
+    again = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=9)
+    np.testing.assert_array_equal(again['labels'].cpu().numpy(), plain['labels'].cpu().numpy())
