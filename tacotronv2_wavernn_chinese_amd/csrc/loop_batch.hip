@@ -22,7 +22,7 @@
 //    8 fc3 rows sit in LDS.  (Two waves per SIMD at 256 registers each, the team2 split, spills ~100-220 registers to
 //    scratch here: measured with -Rpass-analysis.)  What team2 gave to "shadow" waves runs in the same instruction stream,
 //    right after the publish of each phase and before the poll of its exchange: W_hh1.h1' (window 2), W_hh2.h2' (window 3),
-//    sampling noise and the next step's conditioning (window 4).  MFMA issue is asynchronous to the wave's VALU / LDS
+//    the next step's conditioning (window 1, behind the x2 | h1' publish), sampling noise (window 4).  MFMA issue is asynchronous to the wave's VALU / LDS
 //    stream, and nothing needs a hand-off through LDS: gh1, gh2, conditioning, noise stay in the owning thread's registers.
 //  * Phase A (I + GRU1, elementwise) is no longer replicated in every workgroup: each workgroup evaluates its own 16 hidden
 //    units for the R rows and publishes x2 and h1' (one more exchange than team2, but no 8 KB/step/row conditioning stream:
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             const unsigned par = epoch & 1u;
             if (PROF) prof_last = (unsigned)__builtin_readcyclecounter();
 
-            // ================= window 1: phase A | publish x2, h1' | gather both =================
+            // ================= window 1: phase A | publish x2, h1' | conditioning of the next step | gather both =================
             {
                 // I + GRU1 for (unit, row) (:208-212); gi = u * x_{t-1} + v[t] (algebra: DESIGN.md 3.2)
                 const float xprev = xn[rb];
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
             __syncthreads();   // B3
             PB(14);
 
-            // ================= window 4: phase D (fc2, :220-221) | noise of this step, conditioning of the next | gather fc2 =================
+            // ================= window 4: phase D (fc2, :220-221) | noise of this step | gather fc2 =================
             {
                 f4 sum[NQ];
                 mfma_single<NQ, (NQ == 1 ? 4 : 2), true, DS>(wa + 192, vH1, sum);
