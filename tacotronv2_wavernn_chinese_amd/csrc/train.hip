@@ -492,7 +492,8 @@ __global__ void __launch_bounds__(256) ce_grad_kernel(const float *__restrict__ 
     float *d = dY + (size_t)row * NC;
     for (int c = lane; c < NC; c += 64) d[c] = (expf(p[c] - m) / s - (c == tgt ? 1.0f : 0.0f)) * inv_n;
 }
-__device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ double softplus_d(double x) { return x > 30.0 ? x : log1p(exp(x)); }
+__device__ __forceinline__ double sigm_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 // discretized_mix_logistic_loss (distribution.py:16-84; num_classes 65536, log_scale_min log(1e-14), reduce=True -> mean):
 // loss_row = -logsumexp_k(D_k + log_softmax(logit)_k);  w = softmax_k of that sum;  d/dlogit_j = softmax(logit)_j - w_j;
 // D_k is the arm the reference's masks select (its blends multiply the other arm by 0):
@@ -501,46 +502,53 @@ __device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : lo
 //   cdf_delta > 1e-5: log(cdf_delta)   dD/dplus = s'(plus) / cdf_delta, dD/dmin = -s'(min) / cdf_delta
 //   else: mid - ls - 2 softplus(mid) - log((nc-1)/2)   dD/dmid = 1 - 2 s(mid), dD/dls (direct) = -1
 // with plus/min/mid = exp(-ls) (y - mean +- 1/(nc-1) | 0): d/dmean = -exp(-ls), d/dls = -(value); ls = max(raw, ls_min) passes
-// the gradient to raw where raw >= ls_min (torch.clamp).  One thread per row.
+// the gradient to raw where raw >= ls_min (torch.clamp).  One thread per row, evaluated in DOUBLE: cdf_delta is the difference of two
+// sigmoids 1/65535 apart and its reciprocal scales the gradient -- in fp32 (the reference's arithmetic) that difference carries ~1e-3
+// relative noise, which then dominates every parameter gradient of a MOL model (torch float32 vs float64: 1.1e-4 of the largest entry on
+// I.weight, 3e-2 on d_mels_up for some batches).  The arm selection uses the fp32-rounded cdf_delta the forward loss kernel sees, so the
+// gradient belongs to the loss value that is reported; 30 doubles per row cost nothing next to the GEMMs.
 __global__ void __launch_bounds__(256) mol_grad_kernel(const float *__restrict__ y_hat, const float *__restrict__ yv, int nr, long n_rows,
                                                        float num_classes, float ls_min, float inv_n, float *__restrict__ dY) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= n_rows) return;
     const float *p = y_hat + (size_t)row * 3 * nr;
     float *d = dY + (size_t)row * 3 * nr;
-    const float y = yv[row];
-    float lm = -INFINITY;
-    for (int k = 0; k < nr; ++k) lm = fmaxf(lm, p[k]);
-    float lsum = 0.0f;
-    for (int k = 0; k < nr; ++k) lsum += expf(p[k] - lm);
-    const float lse_logit = lm + logf(lsum);
-    const float hb = 1.0f / (num_classes - 1.0f), log_half = logf((num_classes - 1.0f) / 2.0f);
-    float lp[16], dmean[16], dls[16];
-    float mx = -INFINITY;
+    const double y = (double)yv[row];
+    double lm = -INFINITY;
+    for (int k = 0; k < nr; ++k) lm = fmax(lm, (double)p[k]);
+    double lsum = 0.0;
+    for (int k = 0; k < nr; ++k) lsum += exp((double)p[k] - lm);
+    const double lse_logit = lm + log(lsum);
+    const double hb = 1.0 / ((double)num_classes - 1.0), log_half = log(((double)num_classes - 1.0) / 2.0);
+    double lp[16], dmean[16], dls[16];
+    double mx = -INFINITY;
     for (int k = 0; k < nr; ++k) {
-        const float mean = p[nr + k], raw = p[2 * nr + k];
-        const float ls = fmaxf(raw, ls_min);
-        const float cy = y - mean, inv = expf(-ls);
-        const float plus = inv * (cy + hb), mn = inv * (cy - hb), mid = inv * cy;
-        const float sp = sigm(plus), sn = sigm(mn);
-        const float cdf_delta = sp - sn;
-        float D, dplus = 0.f, dmin = 0.f, dmid = 0.f, ddirect = 0.f;
-        if (y < -0.999f) { D = plus - softplus_t(plus); dplus = 1.0f - sp; }
-        else if (y > 0.999f) { D = -softplus_t(mn); dmin = -sn; }
-        else if (cdf_delta > 1e-5f) { D = logf(fmaxf(cdf_delta, 1e-12f)); dplus = sp * (1.0f - sp) / cdf_delta; dmin = -sn * (1.0f - sn) / cdf_delta; }
-        else { D = mid - ls - 2.0f * softplus_t(mid) - log_half; dmid = 1.0f - 2.0f * sigm(mid); ddirect = -1.0f; }
+        const double mean = (double)p[nr + k], raw = (double)p[2 * nr + k];
+        const double ls = fmax(raw, (double)ls_min);
+        const double cy = y - mean, inv = exp(-ls);
+        const double plus = inv * (cy + hb), mn = inv * (cy - hb), mid = inv * cy;
+        const double sp = sigm_d(plus), sn = sigm_d(mn);
+        const double cdf_delta = sp - sn;
+        // the arm the FORWARD (fp32, losses.hip / the reference) takes: its cdf_delta is the fp32 difference of fp32 sigmoids
+        const float invf = expf(-fmaxf(p[2 * nr + k], ls_min)), cyf = yv[row] - p[nr + k];
+        const float cdf_f = 1.0f / (1.0f + expf(-(invf * (cyf + (float)hb)))) - 1.0f / (1.0f + expf(-(invf * (cyf - (float)hb))));
+        double D, dplus = 0.0, dmin = 0.0, dmid = 0.0, ddirect = 0.0;
+        if (yv[row] < -0.999f) { D = plus - softplus_d(plus); dplus = 1.0 - sp; }
+        else if (yv[row] > 0.999f) { D = -softplus_d(mn); dmin = -sn; }
+        else if (cdf_f > 1e-5f) { const double cd = fmax(cdf_delta, 1e-12); D = log(cd); dplus = sp * (1.0 - sp) / cd; dmin = -sn * (1.0 - sn) / cd; }
+        else { D = mid - ls - 2.0 * softplus_d(mid) - log_half; dmid = 1.0 - 2.0 * sigm_d(mid); ddirect = -1.0; }
         dmean[k] = -inv * (dplus + dmin + dmid);
-        dls[k] = (raw >= ls_min) ? (-(dplus * plus + dmin * mn + dmid * mid) + ddirect) : 0.0f;
-        lp[k] = D + (p[k] - lse_logit);
-        mx = fmaxf(mx, lp[k]);
+        dls[k] = (raw >= (double)ls_min) ? (-(dplus * plus + dmin * mn + dmid * mid) + ddirect) : 0.0;
+        lp[k] = D + ((double)p[k] - lse_logit);
+        mx = fmax(mx, lp[k]);
     }
-    float s = 0.0f;
-    for (int k = 0; k < nr; ++k) s += expf(lp[k] - mx);
+    double s = 0.0;
+    for (int k = 0; k < nr; ++k) s += exp(lp[k] - mx);
     for (int k = 0; k < nr; ++k) {
-        const float w = expf(lp[k] - mx) / s;
-        d[k] = (expf(p[k] - lse_logit) - w) * inv_n;
-        d[nr + k] = -w * dmean[k] * inv_n;
-        d[2 * nr + k] = -w * dls[k] * inv_n;
+        const double w = exp(lp[k] - mx) / s;
+        d[k] = (float)((exp((double)p[k] - lse_logit) - w) * (double)inv_n);
+        d[nr + k] = (float)(-w * dmean[k] * (double)inv_n);
+        d[2 * nr + k] = (float)(-w * dls[k] * (double)inv_n);
     }
 }
 

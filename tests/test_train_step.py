@@ -129,13 +129,14 @@ def test_training_loss_backward_matches_the_reference(name):
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_loop_gradients_from_float64_conditioning(name):
     """wrnn_train_step alone: fed the conditioning of the float64 restatement (rounded to float32), its 16 parameter gradients
-    and d_mels_up / d_aux (what flows back into the upsample network) against float64 autograd -- RAW: 2e-5 of the largest entry
-    (measured 5e-6); MOL: 5e-3 (measured 2.6e-3 on d_mels_up: the discretised likelihood is ill-conditioned in fp32: cdf_plus - cdf_min of two sigmoids
-    1/65535 apart; torch's own float32 evaluation differs from float64 by 1.1e-4 on I.weight).  Also the g == NULL mode
+    and d_mels_up / d_aux (what flows back into the upsample network) against float64 autograd: within 2e-5 of the largest entry
+    (measured: RAW 8e-6, MOL 1.3e-6 -- `mol_grad_kernel` evaluates the discretised likelihood's gradient in double: in fp32, the
+    reference's arithmetic, cdf_plus - cdf_min of two sigmoids 1/65535 apart carries ~1e-3 relative noise and torch's own float32
+    gradients differ from float64 by 1.1e-4 of the largest entry on I.weight).  Also the g == NULL mode
     (forward + loss only) and the replay of the captured step graphs."""
     from tacotronv2_wavernn_chinese_amd import _cabi
     z, c, sd, x, mels, y = _load(name)
-    tol = 2e-5 if c['mode'] == 'RAW' else 5e-3
+    tol = 2e-5
     m = _model(c, sd)
     ref = tr.training_step(sd, c['mode'], x, mels, y, dtype=torch.float64, device='cuda')
     dev = torch.device('cuda:0')
@@ -197,3 +198,59 @@ def test_a_few_optimizer_steps_at_the_reference_batch_size():
     print(f'\n[train] B=32, L=1375: {dt * 1e3:.1f} ms per iteration (forward + backward + Adam) = {B * T * 275 / dt / 1e3:.0f} ksamples/s; '
           f'loss {losses[0]:.4f} -> {losses[-1]:.4f}')
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['RAW', 'MOL'])
+def test_train_step_on_non_default_dims_and_ragged_batch_sizes(mode):
+    """The generic instantiations (`gru_*_step_kernel<0>`: any rnn_dims % 16 == 0) and a batch that is not a multiple of the 32-row
+    tile: rnn 256 / fc 384 / 40 mels / aux 24, B = 5 and B = 35, against float64 autograd on the same conditioning."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+    dims = dict(rnn_dims=256, fc_dims=384, bits=8, pad=2, upsample_factors=(4, 4, 8), feat_dims=40, compute_dims=64,
+                res_out_dims=96, res_blocks=2, hop_length=128, sample_rate=16000)
+    sd = make_state_dict(7, mode=mode, variant='default', **dims)
+    m = WaveRNN(**dims, mode=mode)
+    m.verbose = False
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m.to('cuda:0')
+    m.train()
+    dev = torch.device('cuda:0')
+    for B, T in ((5, 2), (35, 1)):
+        L = T * 128
+        rng = np.random.Generator(np.random.PCG64(B))
+        mels = rng.random((B, 40, T + 4), dtype=np.float32)
+        if mode == 'RAW':
+            lab = rng.integers(0, 256, size=(B, L + 1))
+            x, y = (2.0 * lab[:, :-1] / 255.0 - 1.0).astype(np.float32), lab[:, 1:].astype(np.int64)
+        else:
+            sig = rng.uniform(-1, 1, size=(B, L + 1)).astype(np.float32)
+            x, y = sig[:, :-1].copy(), sig[:, 1:].copy()
+        sd64 = {k: torch.as_tensor(np.asarray(v)).to(dev, torch.float64).requires_grad_(torch.as_tensor(np.asarray(v)).is_floating_point()
+                                                                                          and not k.endswith(('running_mean', 'running_var')))
+                if torch.as_tensor(np.asarray(v)).is_floating_point() else torch.as_tensor(np.asarray(v)) for k, v in sd.items()}
+        mu64, au64 = tr.upsample(sd64, torch.from_numpy(mels).to(dev, torch.float64), upsample_factors=(4, 4, 8), pad=2, training=True)
+        mu64.retain_grad()
+        au64.retain_grad()
+        loss64 = tr.loss_of(mode, tr.loop_forward(sd64, torch.from_numpy(x).to(dev, torch.float64), mu64, au64), torch.from_numpy(y).to(dev))
+        loss64.backward()
+        mu = mu64.detach().float().contiguous()
+        au = au64.detach().float().contiguous()
+        xt = torch.from_numpy(x).to(dev)
+        yt = torch.from_numpy(y).to(dev).to(torch.int32 if mode == 'RAW' else torch.float32).contiguous()
+        ps = [p.detach().contiguous() for p in m._loop_params()]
+        gs = [torch.empty_like(p) for p in ps]
+        dm, da = torch.empty_like(mu), torch.empty_like(au)
+        loss = torch.empty((), device=dev)
+        m._native_handle().train_step([p.data_ptr() for p in ps], [g.data_ptr() for g in gs], xt.data_ptr(), mu.data_ptr(), au.data_ptr(),
+                                      yt.data_ptr(), B, L, loss.data_ptr(), 0, dm.data_ptr(), da.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(loss64)) <= 2e-5 * abs(float(loss64)), (B, float(loss), float(loss64))
+        # Random initial weights put a few of the B*L*(fc1 + fc2) ReLU pre-activations within float32 rounding of zero: float32 and
+        # float64 then disagree about ONE unit's mask at ONE (batch, step) pair, which moves that pair's row of d_mels_up / d_aux by
+        # a few per cent of the tensor's largest entry, and that unit's row of a weight gradient by a few 1e-4 (found with B = 35, T = 1:
+        # the fc2 mask of row (10, 93)).  So: 99 % of the entries within 5e-5 of the largest one, no entry off by more than 0.1 of it.
+        for got, want, nm in [(dm, mu64.grad, 'd_mels_up'), (da, au64.grad, 'd_aux')] + [(g, sd64[k].grad, k) for g, k in zip(gs, _cabi.LOOP_PARAM_KEYS)]:
+            w = want.detach().cpu().numpy()
+            err = np.abs(got.cpu().numpy() - w).reshape(-1) / max(np.abs(w).max(), 1e-12)
+            assert np.quantile(err, 0.99) <= 5e-5 and err.max() <= 0.1, (mode, B, nm, float(np.quantile(err, 0.99)), float(err.max()))
