@@ -251,6 +251,13 @@ int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_p
                     const float *mels_up_dev, const float *aux_dev, const void *y_dev, int32_t B, int64_t L,
                     float *loss_out_dev, float *logits_out_dev, float *d_mels_up_dev, float *d_aux_dev, void *stream);
 
+/* Waits for `stream`, then reports the device-side error word of the team kernels wrnn_train_step launched (WRNN_ERR_BUSY,
+ * WRNN_ERR_TIMEOUT) -- what wrnn_last_timing does for wrnn_generate. */
+int wrnn_sync_status(wrnn_handle *h, void *stream);
+/* The two GRU recurrences of wrnn_train_step run as one persistent XCD-team kernel each where rnn_dims is 512 and the device has
+ * 32-CU teams, else as one kernel per time step replayed from a hipGraph.  on != 0 forces the per-step kernels (tests compare the two). */
+int wrnn_train_force_step_kernels(wrnn_handle *h, int32_t on);
+
 /* Blocks until the last wrnn_generate on this handle finished, then reports
  * HIP-event timings and any device-side error (WRNN_ERR_TIMEOUT). */
 int wrnn_last_timing(wrnn_handle *h, wrnn_timing *out);

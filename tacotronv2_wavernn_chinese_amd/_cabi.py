@@ -29,7 +29,7 @@ ABI_VERSION = 4   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding w
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
                     'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_rows', 'wrnn_epilogue_tables', 'wrnn_loss',
-                    'wrnn_phase_profile', 'wrnn_phase_cycles', 'wrnn_train_step',
+                    'wrnn_phase_profile', 'wrnn_phase_cycles', 'wrnn_train_step', 'wrnn_sync_status', 'wrnn_train_force_step_kernels',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
                     'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
 
@@ -155,6 +155,10 @@ def load_library() -> C.CDLL:
     lib.wrnn_train_step.argtypes = [vp, C.POINTER(LoopParams), C.POINTER(LoopParams), vp, vp, vp, vp, C.c_int32, C.c_int64, vp, vp,
                                     vp, vp, vp]
     lib.wrnn_train_step.restype = C.c_int
+    lib.wrnn_sync_status.argtypes = [vp, vp]
+    lib.wrnn_sync_status.restype = C.c_int
+    lib.wrnn_train_force_step_kernels.argtypes = [vp, C.c_int32]
+    lib.wrnn_train_force_step_kernels.restype = C.c_int
     lib.wrnn_epilogue_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.wrnn_epilogue_tables.restype = C.c_int
     lib.wrnn_loss.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
@@ -316,6 +320,13 @@ class NativeVocoder:
         self._check(self.lib.wrnn_train_step(self._h, C.byref(w), C.byref(g) if g is not None else None, x_ptr, mels_up_ptr, aux_ptr,
                                              y_ptr or None, int(B), int(L), loss_ptr or None, logits_ptr or None,
                                              d_mels_up_ptr or None, d_aux_ptr or None, stream or None))
+
+    def sync_status(self, stream: int):
+        """Waits for the stream; raises WrnnError for a device-side team-kernel error of ``train_step`` (busy GPU / timeout)."""
+        self._check(self.lib.wrnn_sync_status(self._h, stream or None))
+
+    def train_force_step_kernels(self, on: bool):
+        self._check(self.lib.wrnn_train_force_step_kernels(self._h, int(bool(on))))
 
     def loss(self, y_hat_ptr: int, y_ptr: int, n_rows: int, out_ptr: int, stream: int):
         self._check(self.lib.wrnn_loss(self._h, y_hat_ptr, y_ptr, int(n_rows), out_ptr, stream or None))

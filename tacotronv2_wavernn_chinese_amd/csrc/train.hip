@@ -30,6 +30,7 @@ namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
+#define TEAM_H 512   // rnn_dims the team recurrence kernels are built for
 #define GT_M 128
 #define GT_N 128
 #define GT_K 16
@@ -563,6 +564,10 @@ struct WrnnTrainState {
     hipGraphExec_t g_fwd[2] = {nullptr, nullptr}, g_bwd[2] = {nullptr, nullptr};   // [GRU1, GRU2]
     const float *w_hh[2] = {nullptr, nullptr}, *b_hh[2] = {nullptr, nullptr};       // weight pointers baked into the graphs
     hipStream_t cap = nullptr;
+    // persistent team kernels of the recurrences (train_team.hip): mailbox, team-formation words, residency verdict
+    unsigned long long *mail = nullptr;
+    unsigned *ctl = nullptr;
+    int team_checked = 0;      // 0 = not yet, 1 = resident, -1 = not
 };
 
 void wrnn_train_state_free(WrnnTrainState *st) {
@@ -572,6 +577,8 @@ void wrnn_train_state_free(WrnnTrainState *st) {
         if (st->g_bwd[i]) (void)hipGraphExecDestroy(st->g_bwd[i]);
     }
     if (st->cap) (void)hipStreamDestroy(st->cap);
+    if (st->mail) (void)hipFree(st->mail);
+    if (st->ctl) (void)hipFree(st->ctl);
     if (st->ws) (void)hipFree(st->ws);
     delete st;
 }
@@ -649,6 +656,7 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     const int maxN = G > NC ? G : NC;
     const size_t sk_floats = (size_t)16 * G * (H + A);                      // split-K partial products (<= 16 slices of the largest dW)
     const size_t oCS = take((size_t)2 * CS_CHUNKS * maxN), oSK = take(sk_floats);
+    const size_t oIMG = take((size_t)786432);                                // weight image of the recurrence at hand (team kernels)
     const bool fresh = need > st->ws_floats;
     if (fresh) {
         if (st->ws) (void)hipFree(st->ws);
@@ -672,11 +680,51 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     st->B = B; st->L = L;
     for (int i = 0; i < 2; ++i) { st->w_hh[i] = whh[i]; st->b_hh[i] = bhh[i]; }
     (void)hipGetLastError();
+    T_TRY(hipMemsetAsync(h->err_dev, 0, 64, s));   // device error word of the team kernels (wrnn_sync_status)
     auto *fwd_k = H == 512 ? gru_fwd_step_kernel<512> : gru_fwd_step_kernel<0>;
     auto *bwd_k = H == 512 ? gru_bwd_step_kernel<512> : gru_bwd_step_kernel<0>;
     T_TRY(hipFuncSetAttribute((const void *)fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     T_TRY(hipFuncSetAttribute((const void *)bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     const dim3 sgrid(H / GR_UW, (B + 31) / 32);
+    // The recurrences as ONE persistent team kernel each (train_team.hip) where that is possible: rnn_dims 512, 32-CU teams, all four
+    // instantiations resident; otherwise the per-step kernels below, replayed from hipGraphs.
+    int rpb = (B + h->n_teams - 1) / (h->n_teams > 0 ? h->n_teams : 1);
+    if (rpb > 8) rpb = 8;
+    const int nq = rpb <= 4 ? 1 : 2;
+    if (st->team_checked == 0) {
+        st->team_checked = -1;
+        if (H == TEAM_H && h->team_ok && h->n_teams >= 1) {
+            bool ok = true;
+            for (int q = 1; q <= 2 && ok; ++q)
+                for (int bw = 0; bw < 2 && ok; ++bw) {
+                    int blocks = 0;
+                    ok = wrnn_gru_team_occupancy(q, bw != 0, &blocks) == hipSuccess && blocks >= 1;
+                }
+            (void)hipGetLastError();
+            if (ok) {
+                const size_t mg = (size_t)h->n_teams * wrnn_gru_team_mail_granules(2, true);
+                ok = hipMalloc(&st->mail, mg * sizeof(unsigned long long)) == hipSuccess && hipMalloc(&st->ctl, 256) == hipSuccess;
+            }
+            if (ok) st->team_checked = 1;
+        }
+    }
+    const bool use_team = st->team_checked == 1 && H == TEAM_H && !h->train_force_steps;
+    float *img = ws + oIMG;
+    auto recur_team = [&](int i, bool bwd, const float *dHext) -> hipError_t {
+        const Gru &q = gr[i];
+        hipError_t e = wrnn_gru_team_pack(whh[i], img, bwd, s);
+        if (e != hipSuccess) return e;
+        WrnnGruTeamArgs ta{};
+        ta.img = img; ta.bhh = bhh[i]; ta.GI = q.GI; ta.Hs = q.H; ta.HP = q.HP; ta.Rs = q.R; ta.Zs = q.Z; ta.Ns = q.N; ta.GHN = q.GHN;
+        ta.dHext = dHext; ta.dGI = q.dGI; ta.dGH = q.dGH; ta.B = B; ta.L = L; ta.n_teams = h->n_teams; ta.rpb = rpb;
+        ta.mail = st->mail; ta.ctl = st->ctl; ta.err = h->err_dev;
+        if ((e = wrnn_team_gate_enter(h->cfg.device, s)) != hipSuccess) return e;   // team kernels of a device run one after the other
+        e = hipMemsetAsync(st->mail, 0, (size_t)h->n_teams * wrnn_gru_team_mail_granules(nq, bwd) * sizeof(unsigned long long), s);
+        if (e == hipSuccess) e = hipMemsetAsync(st->ctl, 0, 256, s);
+        if (e == hipSuccess) e = wrnn_gru_team_launch(ta, nq, bwd, s);
+        const hipError_t ge = wrnn_team_gate_leave(h->cfg.device, s);
+        return e != hipSuccess ? e : ge;
+    };
     const float *a1 = aux_dev, *a2 = aux_dev + A, *a3 = aux_dev + 2 * A, *a4 = aux_dev + 3 * A;   // aux channel split (:198-199)
 
     // ================= forward (:146-167) =================
@@ -688,6 +736,7 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
         const Gru &q = gr[i];
         hipError_t e = hipMemsetAsync(q.HP, 0, nH * sizeof(float), s);   // h_{-1} = 0 (:141-142); rows t > 0 are overwritten
         if (e != hipSuccess) return e;
+        if (use_team) return recur_team(i, false, nullptr);
         return run_steps(st, &st->g_fwd[i], rebuild, s, [&](hipStream_t cs) {
             for (long t = 0; t < L; ++t)
                 hipLaunchKernelGGL(fwd_k, sgrid, dim3(256), lds_f, cs, q.GI, whh[i], bhh[i], q.H, q.HP, q.R, q.Z, q.N, q.GHN, B, L, H, t);
@@ -758,6 +807,7 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     if (d_aux_dev) T_TRY(gemm(s, false, false, dF1, FC, w->fc1_w + H, H + A, d_aux_dev + 2 * A, R, M, A, FC));
     auto recur_bwd = [&](int i, const float *dHext) -> hipError_t {
         const Gru &q = gr[i];
+        if (use_team) return recur_team(i, true, dHext);
         hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (G + 31) / 32), dim3(256), 0, s, whh[i], q.WhhT, H, G);   // WhhT[j][k] = W_hh[k][j]
         return run_steps(st, &st->g_bwd[i], rebuild, s, [&](hipStream_t cs) {
             for (long t = L - 1; t >= 0; --t)
@@ -791,5 +841,26 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     if (d_mels_up_dev) T_TRY(gemm(s, false, false, dXI, H, w->I_w + 1, IN_I, d_mels_up_dev, F, M, F, H));
     if (d_aux_dev) T_TRY(gemm(s, false, false, dXI, H, w->I_w + 1 + F, IN_I, d_aux_dev, R, M, A, H));
     T_TRY(hipGetLastError());
+    return WRNN_OK;
+}
+
+// Waits for `stream` and reports the device error word of the team kernels launched on this handle since the last call
+// (WRNN_ERR_BUSY / WRNN_ERR_TIMEOUT): what wrnn_last_timing does for wrnn_generate, for callers of wrnn_train_step.
+extern "C" int wrnn_sync_status(wrnn_handle *h, void *stream) {
+    if (!h) return WRNN_ERR_INVALID;
+    T_TRY(hipSetDevice(h->cfg.device));
+    T_TRY(hipStreamSynchronize((hipStream_t)stream));
+    unsigned errw = 0;
+    T_TRY(hipMemcpy(&errw, h->err_dev, sizeof(errw), hipMemcpyDeviceToHost));
+    if (errw == WRNN_DEVERR_BUSY)
+        return tfail(h, WRNN_ERR_BUSY, "a team kernel's workgroups did not all become resident: the GPU is shared with another kernel (retry)");
+    if (errw) return tfail(h, WRNN_ERR_TIMEOUT, "device-side bounded spin gave up (code %u)", errw);
+    return WRNN_OK;
+}
+
+// developer / test switch: != 0 makes wrnn_train_step use the per-step kernels (hipGraph replay) even where the team kernels can run
+extern "C" int wrnn_train_force_step_kernels(wrnn_handle *h, int32_t on) {
+    if (!h) return WRNN_ERR_INVALID;
+    h->train_force_steps = on != 0;
     return WRNN_OK;
 }

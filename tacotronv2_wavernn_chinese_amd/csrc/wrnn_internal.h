@@ -110,6 +110,7 @@ struct wrnn_handle {
     double *loss_partial = nullptr;   // per-block partial sums of wrnn_loss
     size_t loss_cap = 0;
     WrnnTrainState *train = nullptr;
+    bool train_force_steps = false;   // wrnn_train_force_step_kernels
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
     wrnn_timing last{};
@@ -235,6 +236,25 @@ struct WrnnBatchArgs {
     unsigned *err;
     unsigned long long *prof;
 };
+
+// Persistent team kernels of the two GRU recurrences of wrnn_train_step (train_team.hip)
+struct WrnnGruTeamArgs {
+    const float *img;          // weight image of this recurrence for the kernel at hand (wrnn_gru_team_pack)
+    const float *bhh;          // [3H] (forward)
+    const float *GI;           // (B, L, 3H) forward: input part of the gates
+    float *Hs, *HP, *Rs, *Zs, *Ns, *GHN;   // (B, L, H) saved by the forward, read by the backward
+    const float *dHext;        // (B, L, H) backward: gradient flowing into h_t from the layers above
+    float *dGI, *dGH;          // (B, L, 3H) backward outputs
+    int32_t B;
+    int64_t L;
+    int32_t n_teams, rpb;      // rows per team batch (<= 4 * nq)
+    unsigned long long *mail;  // [n_teams][wrnn_gru_team_mail_granules(nq, bwd)]
+    unsigned *ctl, *err;
+};
+size_t wrnn_gru_team_mail_granules(int nq, bool bwd);
+hipError_t wrnn_gru_team_pack(const float *Whh, float *img, bool bwd, hipStream_t s);
+hipError_t wrnn_gru_team_launch(const WrnnGruTeamArgs &a, int nq, bool bwd, hipStream_t s);
+hipError_t wrnn_gru_team_occupancy(int nq, bool bwd, int *blocks_per_cu);
 
 // kernels / launchers (defined in the .hip files)
 // mel_T = frames per row of `mels`, mel_off = index of frame 0 in it: (T, 0) for generate()'s unpadded mels (zero

@@ -113,6 +113,7 @@ class WaveRNN(nn.Module):
         self._native_key = None
         # knobs that are not part of the reference signature
         self.kernel = _cabi.KERNEL_AUTO
+        self.check_device_errors = True   # training_loss waits for its kernels and raises on a device-side error
         self.verbose = True
         self.last_timing: Optional[dict] = None
 
@@ -498,9 +499,11 @@ class _LoopTrainFn(torch.autograd.Function):
         logits = torch.empty((B, L, model.n_classes), dtype=torch.float32, device=dev) if want_logits else None
         ps = [p.detach().contiguous() for p in params]
         with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
             nat.train_step([p.data_ptr() for p in ps], [g.data_ptr() for g in grads], x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(),
-                           y.data_ptr(), B, L, loss.data_ptr(), logits.data_ptr() if want_logits else 0, d_m.data_ptr(), d_a.data_ptr(),
-                           torch.cuda.current_stream(dev).cuda_stream)
+                           y.data_ptr(), B, L, loss.data_ptr(), logits.data_ptr() if want_logits else 0, d_m.data_ptr(), d_a.data_ptr(), st)
+            if model.check_device_errors:
+                nat.sync_status(st)   # waits for the stream: a busy GPU / a timed-out team kernel raises here, not as a silent NaN
         ctx.save_for_backward(d_m, d_a, *grads)
         if want_logits:
             ctx.mark_non_differentiable(logits)

@@ -254,3 +254,49 @@ def test_train_step_on_non_default_dims_and_ragged_batch_sizes(mode):
             w = want.detach().cpu().numpy()
             err = np.abs(got.cpu().numpy() - w).reshape(-1) / max(np.abs(w).max(), 1e-12)
             assert np.quantile(err, 0.99) <= 5e-5 and err.max() <= 0.1, (mode, B, nm, float(np.quantile(err, 0.99)), float(err.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [3, 32, 61])
+def test_team_recurrence_kernels_equal_the_step_kernels(B):
+    """The persistent XCD-team kernels of the two GRU recurrences (train_team.hip; 4 or 8 rows per team, K-split backward with a
+    reduce-scatter) against the per-step kernels (wrnn_train_force_step_kernels): same loss, same fc3 outputs, gradients equal to
+    fp32 summation-order noise.  B = 3: one partial quad; 32: 8 teams x 4 rows; 61: 8 rows per team with a ragged last batch."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    c = CASES['train_raw_peaky_b4_t5']
+    sd = make_state_dict(0, mode='RAW', variant='peaky', bits=10)
+    m = _model(c, sd)
+    dev = torch.device('cuda:0')
+    T = 2
+    L = T * 275
+    rng = np.random.Generator(np.random.PCG64(100 + B))
+    lab = rng.integers(0, 1024, size=(B, L + 1))
+    x = torch.from_numpy((2.0 * lab[:, :-1] / 1023.0 - 1.0).astype(np.float32)).to(dev)
+    y = torch.from_numpy(lab[:, 1:].astype(np.int32)).to(dev)
+    mu = torch.from_numpy(rng.random((B, L, 80), dtype=np.float32)).to(dev)
+    au = torch.from_numpy(rng.standard_normal((B, L, 128)).astype(np.float32)).to(dev)
+    ps = [p.detach().contiguous() for p in m._loop_params()]
+    nat = m._native_handle()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    res = {}
+    for mode in ('steps', 'team'):
+        nat.train_force_step_kernels(mode == 'steps')
+        gs = [torch.zeros_like(p) for p in ps]
+        dm, da = torch.zeros_like(mu), torch.zeros_like(au)
+        loss = torch.zeros((), device=dev)
+        logits = torch.zeros((B, L, 1024), device=dev)
+        for _ in range(2):
+            nat.train_step([p.data_ptr() for p in ps], [g.data_ptr() for g in gs], x.data_ptr(), mu.data_ptr(), au.data_ptr(), y.data_ptr(), B, L,
+                           loss.data_ptr(), logits.data_ptr(), dm.data_ptr(), da.data_ptr(), st)
+            nat.sync_status(st)
+        res[mode] = (float(loss), logits.cpu().numpy(), [g.cpu().numpy() for g in gs], dm.cpu().numpy(), da.cpu().numpy())
+    nat.train_force_step_kernels(False)
+    a, b = res['steps'], res['team']
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0])
+    assert np.abs(a[1] - b[1]).max() <= 2e-5 * np.abs(a[1]).max()
+    worst = 0.0
+    for ga, gb, k in list(zip(a[2], b[2], _cabi.LOOP_PARAM_KEYS)) + [(a[3], b[3], 'd_mels_up'), (a[4], b[4], 'd_aux')]:
+        err = float(np.abs(ga - gb).max() / max(np.abs(ga).max(), 1e-12))
+        worst = max(worst, err)
+        assert err <= 2e-5, (k, err)
+    print(f'\n[train] team vs step recurrence kernels, B={B}: worst gradient difference {worst:.2e} of the largest entry')
