@@ -776,9 +776,12 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     // the chip, partial products summed in slice order (deterministic)
     auto gemm_tn = [&](const float *Am, long lda, const float *Bm, long ldb, float *Cm, long ldc, int Mo, int No) -> hipError_t {
         const int tiles = ((Mo + GT_M - 1) / GT_M) * ((No + GT_N - 1) / GT_N);
-        int S = tiles >= 128 ? 1 : (256 + tiles - 1) / tiles;
-        if (S > 16) S = 16;
-        if (S <= 1 || (size_t)S * Mo * No > sk_floats) return gemm(s, true, false, Am, lda, Bm, ldb, Cm, ldc, Mo, No, (int)M);
+        // slices x tiles <= 256 workgroups = one pass over the chip's CUs (with ceil() 48 tiles x 6 slices = 288 workgroups ran as one
+        // full pass + a 12 % second one: 0.56 of the machine)
+        int S = tiles >= 128 ? 1 : 256 / tiles;
+        if (S > 64) S = 64;
+        while (S > 1 && (size_t)S * Mo * No > sk_floats) --S;
+        if (S <= 1) return gemm(s, true, false, Am, lda, Bm, ldb, Cm, ldc, Mo, No, (int)M);
         const long per = ((M + S - 1) / S + GT_K - 1) / GT_K * GT_K;
         // one launch, blockIdx.z = slice (slices past the end of K write zeros)
         hipError_t e = gemm(s, true, false, Am, lda, Bm, ldb, sk_part, No, Mo, No, (int)M, 0, nullptr, 0, S, (int)per, (long)Mo * No);
