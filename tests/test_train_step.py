@@ -257,11 +257,11 @@ def test_train_step_on_non_default_dims_and_ragged_batch_sizes(mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B', [3, 32, 61])
+@pytest.mark.parametrize('B', [3, 32, 61, 70])
 def test_team_recurrence_kernels_equal_the_step_kernels(B):
     """The persistent XCD-team kernels of the two GRU recurrences (train_team.hip; 4 or 8 rows per team, K-split backward with a
     reduce-scatter) against the per-step kernels (wrnn_train_force_step_kernels): same loss, same fc3 outputs, gradients equal to
-    fp32 summation-order noise.  B = 3: one partial quad; 32: 8 teams x 4 rows; 61: 8 rows per team with a ragged last batch."""
+    fp32 summation-order noise.  B = 3: one partial quad; 32: 8 teams x 4 rows; 61: 8 rows per team with a ragged last batch; 70: 9 batches, team 0 runs two of them back to back."""
     from tacotronv2_wavernn_chinese_amd import _cabi
     c = CASES['train_raw_peaky_b4_t5']
     sd = make_state_dict(0, mode='RAW', variant='peaky', bits=10)
