@@ -143,7 +143,9 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_fwd_kernel(WrnnGruTeamArg
                 }
             }
             hprev = h;
-            if (t + 1 < a.L) {
+            {   // also after the LAST step, whose result nobody needs: the gather is what keeps the 32 workgroups within one publish
+                // of each other -- without it a fast workgroup starts the team's next batch and overwrites the parity region a slow one
+                // is still reading for step L - 2 (found with B = 70: 9 batches on 8 teams)
                 u4v gx[1][NM];
                 const unsigned offs[1] = {par * F::RG * 8u};
                 gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 31u);
@@ -241,8 +243,7 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
                 }
                 Gs[prow * 48 + pu] = dpr; Gs[prow * 48 + 16 + pu] = dpz; Gs[prow * 48 + 32 + pu] = dghn;
             }
-            if (t == 0) break;   // the carry into t = -1 is not needed
-            __syncthreads();
+            __syncthreads();   // (t == 0 included: its carry is not needed, its exchange keeps the team in lock-step across batches)
             // ---- partial carry of ALL 512 units from the own 48 gate rows: P[row][out] = sum_k G[row][k] W[k][out]
             f4 acc[2][NQ];
 #pragma unroll
