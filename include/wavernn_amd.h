@@ -251,6 +251,19 @@ int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_p
                     const float *mels_up_dev, const float *aux_dev, const void *y_dev, int32_t B, int64_t L,
                     float *loss_out_dev, float *logits_out_dev, float *d_mels_up_dev, float *d_aux_dev, void *stream);
 
+/* The same computation split where autograd splits it -- so that the reference's own training loop runs unchanged
+ * (`y_hat = model(x, m); loss = loss_func(y_hat, y); loss.backward()`, wavernn_train.py:103-122, with ANY loss on y_hat):
+ *   wrnn_train_forward   forward() from the conditioning on (:145-167): logits_out_dev (B, L, n_classes); every activation stays in
+ *                        the handle's workspace
+ *   wrnn_train_backward  given d_logits_dev (B, L, n_classes) = d loss / d y_hat: the 16 parameter gradients g (overwritten) and the
+ *                        gradients w.r.t. the conditioning (either may be NULL).  Must follow a wrnn_train_forward on the same handle
+ *                        with the same B, L, inputs and parameters, with no other training call in between (WRNN_ERR_STATE otherwise). */
+int wrnn_train_forward(wrnn_handle *h, const wrnn_loop_params *w, const float *x_dev, const float *mels_up_dev, const float *aux_dev,
+                       int32_t B, int64_t L, float *logits_out_dev, void *stream);
+int wrnn_train_backward(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_params *g, const float *d_logits_dev,
+                        const float *x_dev, const float *mels_up_dev, const float *aux_dev, int32_t B, int64_t L,
+                        float *d_mels_up_dev, float *d_aux_dev, void *stream);
+
 /* Waits for `stream`, then reports the device-side error word of the team kernels wrnn_train_step launched (WRNN_ERR_BUSY,
  * WRNN_ERR_TIMEOUT) -- what wrnn_last_timing does for wrnn_generate. */
 int wrnn_sync_status(wrnn_handle *h, void *stream);

@@ -29,7 +29,7 @@ ABI_VERSION = 4   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding w
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
                     'wrnn_last_timing', 'wrnn_n_classes', 'wrnn_loop_weight_bytes', 'wrnn_last_error',
                     'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_rows', 'wrnn_epilogue_tables', 'wrnn_loss',
-                    'wrnn_phase_profile', 'wrnn_phase_cycles', 'wrnn_train_step', 'wrnn_sync_status', 'wrnn_train_force_step_kernels',
+                    'wrnn_phase_profile', 'wrnn_phase_cycles', 'wrnn_train_step', 'wrnn_train_forward', 'wrnn_train_backward', 'wrnn_sync_status', 'wrnn_train_force_step_kernels',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
                     'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
 
@@ -155,6 +155,10 @@ def load_library() -> C.CDLL:
     lib.wrnn_train_step.argtypes = [vp, C.POINTER(LoopParams), C.POINTER(LoopParams), vp, vp, vp, vp, C.c_int32, C.c_int64, vp, vp,
                                     vp, vp, vp]
     lib.wrnn_train_step.restype = C.c_int
+    lib.wrnn_train_forward.argtypes = [vp, C.POINTER(LoopParams), vp, vp, vp, C.c_int32, C.c_int64, vp, vp]
+    lib.wrnn_train_forward.restype = C.c_int
+    lib.wrnn_train_backward.argtypes = [vp, C.POINTER(LoopParams), C.POINTER(LoopParams), vp, vp, vp, vp, C.c_int32, C.c_int64, vp, vp, vp]
+    lib.wrnn_train_backward.restype = C.c_int
     lib.wrnn_sync_status.argtypes = [vp, vp]
     lib.wrnn_sync_status.restype = C.c_int
     lib.wrnn_train_force_step_kernels.argtypes = [vp, C.c_int32]
@@ -320,6 +324,17 @@ class NativeVocoder:
         self._check(self.lib.wrnn_train_step(self._h, C.byref(w), C.byref(g) if g is not None else None, x_ptr, mels_up_ptr, aux_ptr,
                                              y_ptr or None, int(B), int(L), loss_ptr or None, logits_ptr or None,
                                              d_mels_up_ptr or None, d_aux_ptr or None, stream or None))
+
+    def train_forward(self, w_ptrs, x_ptr: int, mels_up_ptr: int, aux_ptr: int, B: int, L: int, logits_ptr: int, stream: int):
+        w = LoopParams(*[int(p) for p in w_ptrs])
+        self._check(self.lib.wrnn_train_forward(self._h, C.byref(w), x_ptr, mels_up_ptr, aux_ptr, int(B), int(L), logits_ptr, stream or None))
+
+    def train_backward(self, w_ptrs, g_ptrs, d_logits_ptr: int, x_ptr: int, mels_up_ptr: int, aux_ptr: int, B: int, L: int,
+                       d_mels_up_ptr: int, d_aux_ptr: int, stream: int):
+        w = LoopParams(*[int(p) for p in w_ptrs])
+        g = LoopParams(*[int(p) for p in g_ptrs])
+        self._check(self.lib.wrnn_train_backward(self._h, C.byref(w), C.byref(g), d_logits_ptr, x_ptr, mels_up_ptr, aux_ptr, int(B), int(L),
+                                                 d_mels_up_ptr or None, d_aux_ptr or None, stream or None))
 
     def sync_status(self, stream: int):
         """Waits for the stream; raises WrnnError for a device-side team-kernel error of ``train_step`` (busy GPU / timeout)."""

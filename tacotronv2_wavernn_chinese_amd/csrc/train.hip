@@ -568,6 +568,7 @@ struct WrnnTrainState {
     unsigned long long *mail = nullptr;
     unsigned *ctl = nullptr;
     int team_checked = 0;      // 0 = not yet, 1 = resident, -1 = not
+    bool fwd_valid = false;    // the workspace holds the activations of a forward pass for (B, L)
 };
 
 void wrnn_train_state_free(WrnnTrainState *st) {
@@ -624,12 +625,16 @@ hipError_t run_steps(WrnnTrainState *st, hipGraphExec_t *slot, bool rebuild, hip
 
 }  // namespace
 
-extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_params *g, const float *x_dev, const float *mels_up_dev,
-                               const float *aux_dev, const void *y_dev, int32_t B, int64_t L, float *loss_out_dev, float *logits_out_dev,
-                               float *d_mels_up_dev, float *d_aux_dev, void *stream) {
+// phase bit 0: the forward pass (keeps every activation in the workspace); bit 1: the backward pass, from dY_ext (the gradient of
+// the caller's loss w.r.t. the fc3 outputs) or, when that is null, from the gradient of the training script's own loss on y_dev
+static int train_impl(wrnn_handle *h, int phase, const wrnn_loop_params *w, const wrnn_loop_params *g, const float *x_dev, const float *mels_up_dev,
+                      const float *aux_dev, const void *y_dev, const float *dY_ext, int32_t B, int64_t L, float *loss_out_dev, float *logits_out_dev,
+                      float *d_mels_up_dev, float *d_aux_dev, void *stream) {
     if (!h) return WRNN_ERR_INVALID;
+    const bool do_fwd = (phase & 1) != 0, do_bwd = (phase & 2) != 0;
     if (!w || !x_dev || !mels_up_dev || !aux_dev || B < 1 || L < 1) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: bad arguments");
-    if (g && (!y_dev || !loss_out_dev)) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: gradients need targets and a loss output");
+    if (do_bwd && !g) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_backward: no gradient outputs");
+    if (do_bwd && !dY_ext && (!y_dev || !loss_out_dev)) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: gradients need targets and a loss output");
     const WrnnDims &d = h->d;
     const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, NC = d.NC;
     if (H % 16 != 0 || FC < 1) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_step: rnn_dims must be a multiple of 16");
@@ -658,6 +663,8 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     const size_t oCS = take((size_t)2 * CS_CHUNKS * maxN), oSK = take(sk_floats);
     const size_t oIMG = take((size_t)786432);                                // weight image of the recurrence at hand (team kernels)
     const bool fresh = need > st->ws_floats;
+    if (!do_fwd && (fresh || !st->fwd_valid || st->B != B || st->L != L))
+        return tfail(h, WRNN_ERR_STATE, "wrnn_train_backward: no matching wrnn_train_forward before it (same handle, B, L)");
     if (fresh) {
         if (st->ws) (void)hipFree(st->ws);
         st->ws = nullptr; st->ws_floats = 0;
@@ -680,7 +687,7 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     st->B = B; st->L = L;
     for (int i = 0; i < 2; ++i) { st->w_hh[i] = whh[i]; st->b_hh[i] = bhh[i]; }
     (void)hipGetLastError();
-    T_TRY(hipMemsetAsync(h->err_dev, 0, 64, s));   // device error word of the team kernels (wrnn_sync_status)
+    if (do_fwd) T_TRY(hipMemsetAsync(h->err_dev, 0, 64, s));   // device error word of the team kernels (wrnn_sync_status)
     auto *fwd_k = H == 512 ? gru_fwd_step_kernel<512> : gru_fwd_step_kernel<0>;
     auto *bwd_k = H == 512 ? gru_bwd_step_kernel<512> : gru_bwd_step_kernel<0>;
     T_TRY(hipFuncSetAttribute((const void *)fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
@@ -728,6 +735,8 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     const float *a1 = aux_dev, *a2 = aux_dev + A, *a3 = aux_dev + 2 * A, *a4 = aux_dev + 3 * A;   // aux channel split (:198-199)
 
     // ================= forward (:146-167) =================
+    if (do_fwd) {
+    st->fwd_valid = false;
     // x = I(cat[x, mels, a1])
     T_TRY(gemm(s, false, true, x_dev, 1, w->I_w, IN_I, XI, H, M, H, 1, 0, w->I_b));
     T_TRY(gemm(s, false, true, mels_up_dev, F, w->I_w + 1, IN_I, XI, H, M, H, F, 1));
@@ -759,15 +768,21 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     T_TRY(gemm(s, false, true, F2, FC, w->fc3_w, FC, Y, NC, M, NC, FC, 0, w->fc3_b));
     if (y_dev && loss_out_dev)
         if (int rc = wrnn_loss(h, Y, y_dev, M, loss_out_dev, stream)) return rc;
-    if (!g) return WRNN_OK;
+    st->fwd_valid = true;
+    }
+    if (!do_bwd) return WRNN_OK;
 
     // ================= backward =================
-    const float inv_n = 1.0f / (float)M;
-    if (d.mode == WRNN_MODE_RAW)
-        hipLaunchKernelGGL(ce_grad_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, Y, (const int32_t *)y_dev, NC, M, inv_n, dY);
-    else
-        hipLaunchKernelGGL(mol_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, Y, (const float *)y_dev, NC / 3, M, 65536.0f,
-                           -32.23619130191664f, inv_n, dY);
+    if (dY_ext) {
+        dY = const_cast<float *>(dY_ext);   // read only below
+    } else {
+        const float inv_n = 1.0f / (float)M;
+        if (d.mode == WRNN_MODE_RAW)
+            hipLaunchKernelGGL(ce_grad_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, Y, (const int32_t *)y_dev, NC, M, inv_n, dY);
+        else
+            hipLaunchKernelGGL(mol_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, Y, (const float *)y_dev, NC / 3, M, 65536.0f,
+                               -32.23619130191664f, inv_n, dY);
+    }
     auto colsum = [&](const float *Am, long lda, int N, float *out) {
         hipLaunchKernelGGL(col_sum_part_kernel, dim3((N + 63) / 64, CS_CHUNKS), dim3(256), 0, s, Am, lda, M, N, cs_part);
         hipLaunchKernelGGL(col_sum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, cs_part, N, out);
@@ -845,6 +860,25 @@ extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const 
     if (d_aux_dev) T_TRY(gemm(s, false, false, dXI, H, w->I_w + 1 + F, IN_I, d_aux_dev, R, M, A, H));
     T_TRY(hipGetLastError());
     return WRNN_OK;
+}
+
+extern "C" int wrnn_train_step(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_params *g, const float *x_dev, const float *mels_up_dev,
+                               const float *aux_dev, const void *y_dev, int32_t B, int64_t L, float *loss_out_dev, float *logits_out_dev,
+                               float *d_mels_up_dev, float *d_aux_dev, void *stream) {
+    return train_impl(h, g ? 3 : 1, w, g, x_dev, mels_up_dev, aux_dev, y_dev, nullptr, B, L, loss_out_dev, logits_out_dev, d_mels_up_dev, d_aux_dev, stream);
+}
+
+extern "C" int wrnn_train_forward(wrnn_handle *h, const wrnn_loop_params *w, const float *x_dev, const float *mels_up_dev, const float *aux_dev,
+                                  int32_t B, int64_t L, float *logits_out_dev, void *stream) {
+    if (h && !logits_out_dev) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_forward: logits_out_dev is the result");
+    return train_impl(h, 1, w, nullptr, x_dev, mels_up_dev, aux_dev, nullptr, nullptr, B, L, nullptr, logits_out_dev, nullptr, nullptr, stream);
+}
+
+extern "C" int wrnn_train_backward(wrnn_handle *h, const wrnn_loop_params *w, const wrnn_loop_params *g, const float *d_logits_dev,
+                                   const float *x_dev, const float *mels_up_dev, const float *aux_dev, int32_t B, int64_t L,
+                                   float *d_mels_up_dev, float *d_aux_dev, void *stream) {
+    if (h && !d_logits_dev) return tfail(h, WRNN_ERR_INVALID, "wrnn_train_backward: d_logits_dev missing");
+    return train_impl(h, 2, w, g, x_dev, mels_up_dev, aux_dev, nullptr, d_logits_dev, B, L, nullptr, nullptr, d_mels_up_dev, d_aux_dev, stream);
 }
 
 // Waits for `stream` and reports the device error word of the team kernels launched on this handle since the last call

@@ -168,7 +168,16 @@ class WaveRNN(nn.Module):
         return self._native
 
     def forward(self, x, mels):
-        """Teacher-forced pass of the reference (``forward``, :131-167) on the hot path's own kernels: ``x`` (B, L) is the
+        """``forward`` of the reference (:131-167).
+
+        * ``self.training`` and gradients enabled (what ``y_hat = model(x, m)`` is in the reference's training loop,
+          ``wavernn_train.py:103-110``): the DIFFERENTIABLE pass -- BatchNorm on batch statistics like the reference module in
+          train() mode, loop layers in ``wrnn_train_forward``; the returned y_hat (B, L, n_classes) carries an autograd graph whose
+          backward is ``wrnn_train_backward``, so ``loss_func(y_hat, y).backward()`` with ANY torch loss fills every ``.grad``: the
+          reference's training script runs unchanged (``training_loss`` fuses the script's own loss and its gradient into one call).
+        * otherwise (``eval()`` or ``torch.no_grad()``): the teacher-forced pass on the hot path's own loop kernels, see below.
+
+        Teacher-forced pass on the loop kernels: ``x`` (B, L) is the
         input sample sequence, ``mels`` (B, n_mels, T + 2*pad) the mel window already padded with ``pad`` context frames on
         both sides (what the training collate hands over, :143), L = T * hop.  Returns the fc3 outputs (B, L, n_classes) --
         logits (RAW) / mixture parameters (MOL) -- as a float32 tensor on the model's device.  Inference only (no autograd
@@ -183,6 +192,12 @@ class WaveRNN(nn.Module):
         if T < 1 or x_t.shape != (mels_t.size(0), T * self.hop_length):
             raise ValueError(f'x must be (B, {max(T, 0) * self.hop_length}) for mels {tuple(mels_t.shape)} (pad {self.pad}, hop {self.hop_length})')
         self.step += 1
+        if self.training and torch.is_grad_enabled():
+            dev = next(self.parameters()).device
+            if dev.type != 'cuda':
+                raise RuntimeError('forward() in training mode needs the model on the MI355X (no CPU path in this package)')
+            mels_up, aux = self.upsample_torch(mels_t.to(device=dev, dtype=torch.float32))
+            return _LoopForwardFn.apply(self, x_t.to(device=dev).contiguous(), mels_up.contiguous(), aux.contiguous(), *self._loop_params())
         xs = x_t.detach().cpu().numpy()
         x_forced = np.zeros((xs.shape[1], xs.shape[0]), np.float32)
         x_forced[:-1] = xs[:, 1:].T                      # the value fed to step t + 1 is x[:, t + 1]
@@ -514,3 +529,42 @@ class _LoopTrainFn(torch.autograd.Function):
     def backward(ctx, g_loss, *unused):
         d_m, d_a, *grads = ctx.saved_tensors
         return (None, None, None, None, d_m * g_loss, d_a * g_loss) + tuple(g * g_loss for g in grads)
+
+
+class _LoopForwardFn(torch.autograd.Function):
+    """y_hat = loop layers(x, mels_up, aux; params): ``wrnn_train_forward`` / ``wrnn_train_backward`` (activations stay in the handle's
+    workspace between the two, so backward must be the next training call on the model -- what a training loop does)."""
+
+    @staticmethod
+    def forward(ctx, model, x, mels_up, aux, *params):
+        nat = model._native_handle()
+        dev = x.device
+        B, L = x.shape
+        logits = torch.empty((B, L, model.n_classes), dtype=torch.float32, device=dev)
+        ps = [p.detach().contiguous() for p in params]
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            nat.train_forward([p.data_ptr() for p in ps], x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(), B, L, logits.data_ptr(), st)
+            if model.check_device_errors:
+                nat.sync_status(st)
+        ctx.model = model
+        ctx.save_for_backward(x, mels_up, aux, *ps)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        x, mels_up, aux, *ps = ctx.saved_tensors
+        model = ctx.model
+        nat = model._native_handle()
+        dev = x.device
+        B, L = x.shape
+        grads = [torch.empty_like(p) for p in ps]
+        d_m, d_a = torch.empty_like(mels_up), torch.empty_like(aux)
+        dl = d_logits.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            nat.train_backward([p.data_ptr() for p in ps], [g.data_ptr() for g in grads], dl.data_ptr(), x.data_ptr(), mels_up.data_ptr(),
+                               aux.data_ptr(), B, L, d_m.data_ptr(), d_a.data_ptr(), st)
+            if model.check_device_errors:
+                nat.sync_status(st)
+        return (None, None, d_m, d_a) + tuple(grads)

@@ -299,7 +299,45 @@ def test_team_recurrence_kernels_equal_the_step_kernels(B):
         e = np.abs(ga - gb).reshape(-1) / max(np.abs(ga).max(), 1e-12)
         err = float(e.max())
         worst = max(worst, err)
-        # summation-order noise is ~5e-6; a ReLU pre-activation within that noise of zero flips one unit's mask at one (batch, step)
-        # pair between the two variants and moves the affected entries by ~1e-4 (seen at B = 70: 7.6e-5 on I.weight)
-        assert float(np.quantile(e, 0.99)) <= 2e-5 and err <= 5e-4, (k, float(np.quantile(e, 0.99)), err)
+        # fp32 summation-order noise: ~5e-6 at B <= 61, 3e-5 (99th percentile) / 8e-5 (max) at B = 70 -- against float64 autograd BOTH
+        # variants sit at 2e-4 (team) / 5e-4 (steps) of the largest entry there (38 500 rows, the "peaky" fc3 x 8 weights)
+        assert float(np.quantile(e, 0.99)) <= 1e-4 and err <= 1e-3, (k, float(np.quantile(e, 0.99)), err)
     print(f'\n[train] team vs step recurrence kernels, B={B}: worst gradient difference {worst:.2e} of the largest entry')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_the_reference_training_loop_body_runs_unchanged(name):
+    """`y_hat = model(x, m)` in train() mode is differentiable (wrnn_train_forward / wrnn_train_backward behind autograd), so the loop
+    body of wavernn_train.py:103-122 -- its reshaping, torch's own F.cross_entropy / a torch restatement of the MOL loss,
+    loss.backward() -- runs as written.  Same loss and gradients as the reference golden; y_hat equals the reference's train-mode
+    forward output; in eval() / no_grad the inference-kernel pass is used and gives the eval-mode output."""
+    import torch.nn.functional as F
+    z, c, sd, x, mels, y = _load(name)
+    m = _model(c, sd)
+    dev = torch.device('cuda:0')
+    xt, mt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(mels).to(dev), torch.from_numpy(y).to(dev)
+    y_hat = m(xt, mt)
+    assert y_hat.requires_grad and tuple(y_hat.shape) == (c['B'], c['T'] * 275, m.n_classes)
+    if m.mode == 'RAW':                                      # wavernn_train.py:112-121
+        loss = F.cross_entropy(y_hat.transpose(1, 2).unsqueeze(-1), yt.long().unsqueeze(-1))
+    else:
+        loss = tr.discretized_mix_logistic_loss(y_hat, yt.float())
+    m.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
+    worst = _check_against_golden(z, float(loss.detach()), y_hat.detach().cpu().numpy(), grads, 1e-3)
+    # the fused path gives the same thing
+    m.zero_grad()
+    loss2 = m.training_loss(x, mels, y)
+    loss2.backward()
+    assert abs(float(loss2) - float(loss.detach())) <= 2e-6 * abs(float(loss2))
+    for k, p in m.named_parameters():
+        g2 = p.grad.detach().cpu().numpy()
+        tol = 2e-3 if c['mode'] == 'MOL' else 2e-5           # MOL: torch's fp32 loss gradient vs the double-precision mol_grad_kernel
+        assert np.abs(g2 - grads[k]).max() <= tol * max(np.abs(g2).max(), 1e-12), k
+    m.eval()
+    with torch.no_grad():
+        ev = m(xt, mt)
+    assert not ev.requires_grad and tuple(ev.shape) == tuple(y_hat.shape)
+    print(f'\n[train {name}] unchanged loop body: loss {float(loss.detach()):.6f}, worst gradient sample error vs the reference digests {worst:.2e}')
