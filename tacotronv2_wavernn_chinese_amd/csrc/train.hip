@@ -13,13 +13,17 @@
 //
 // Kernels here:
 //   sgemm_kernel<TA,TB>   C = (beta) C + A.B (+ bias) (relu): 128x128x16 block tile, 4 waves x (2x2) v_mfma_f32_32x32x2f32 tiles,
-//                         operands staged through LDS k-major (conflict-free operand reads), register double-buffered global loads.
-//                         fp32 in, fp32 accumulate: the bound is the fp32 matrix peak (157 TFLOP/s).
+//                         operands staged through LDS k-major (conflict-free operand reads), register double-buffered global loads,
+//                         optional split-K over blockIdx.z (weight gradients).  fp32 in, fp32 accumulate: the bound is the fp32
+//                         matrix peak (157 TFLOP/s); measured 111 TFLOP/s (forward / input gradients), 65 (weight gradients).
+//   the recurrences       train_team.hip: one persistent XCD-team kernel per recurrence and direction (rnn_dims 512).  Fallback here:
 //   gru_fwd_step_kernel   one launch per time step: gh = h_{t-1} . W_hh^T for 4 hidden units x 32 batch rows per workgroup
-//                         (weights + h_{t-1} through LDS), gates, h_t; saves r, z, n, gh_n and h for the backward pass.
+//                         (weights + h_{t-1} through LDS, v_mfma_f32_16x16x4f32), gates, h_t; saves r, z, n, gh_n, h for the backward.
 //   gru_bwd_step_kernel   one launch per time step, t = L-1 .. 0: carry = dGH_{t+1} . W_hh (+ dH_{t+1} z), gate derivatives of step t.
-//   ce_grad / mol_grad    d(mean loss) / d(fc3 outputs); col_sum (bias gradients); small elementwise helpers.
-// The step launches are launch-bound (a few us of work each): they are captured ONCE per (B, L) into hipGraphs and replayed.
+//                         The step launches are captured ONCE per (B, L) into hipGraphs and replayed.
+//   ce_grad / mol_grad    d(mean loss) / d(fc3 outputs) (the MOL one in double); col_sum (bias gradients); small elementwise helpers.
+// Entry points: wrnn_train_step (forward + the script's loss + backward in one call), wrnn_train_forward / wrnn_train_backward (the same
+// split where autograd splits it), wrnn_sync_status.
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
