@@ -19,3 +19,13 @@ voc_gen_at_checkpoint = 5
 voc_gen_batched = False
 voc_target = 11_000
 voc_overlap = 550
+
+# training (wavernn_hparams.py:5, :44-52)
+feature_path = './wavernn_training_data.txt'
+voc_batch_size = 32
+voc_lr = 1e-4
+voc_checkpoint_every = 1000
+voc_total_steps = 500_000
+voc_test_samples = 50
+voc_seq_len = hop_length * 5
+voc_clip_grad_norm = 4
