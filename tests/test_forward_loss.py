@@ -44,6 +44,7 @@ def _model(fx, kernel):
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in fx['state_dict'].items()})
     m.to('cuda:0')
     m.kernel = {'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[kernel]
+    m.eval()   # the goldens are the reference's eval-mode forward; in train() mode forward() is the differentiable pass (test_train_step.py)
     return m
 
 

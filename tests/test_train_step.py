@@ -295,13 +295,20 @@ def test_team_recurrence_kernels_equal_the_step_kernels(B):
     assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0])
     assert np.abs(a[1] - b[1]).max() <= 2e-5 * np.abs(a[1]).max()
     worst = 0.0
-    for ga, gb, k in list(zip(a[2], b[2], _cabi.LOOP_PARAM_KEYS)) + [(a[3], b[3], 'd_mels_up'), (a[4], b[4], 'd_aux')]:
+    for ga, gb, k in zip(a[2], b[2], _cabi.LOOP_PARAM_KEYS):
         e = np.abs(ga - gb).reshape(-1) / max(np.abs(ga).max(), 1e-12)
-        err = float(e.max())
-        worst = max(worst, err)
-        # fp32 summation-order noise: ~5e-6 at B <= 61, 3e-5 (99th percentile) / 8e-5 (max) at B = 70 -- against float64 autograd BOTH
-        # variants sit at 2e-4 (team) / 5e-4 (steps) of the largest entry there (38 500 rows, the "peaky" fc3 x 8 weights)
-        assert float(np.quantile(e, 0.99)) <= 1e-4 and err <= 1e-3, (k, float(np.quantile(e, 0.99)), err)
+        worst = max(worst, float(e.max()))
+        assert float(np.quantile(e, 0.99)) <= 1e-4 and float(e.max()) <= 1e-3, (k, float(np.quantile(e, 0.99)), float(e.max()))
+    # d_mels_up / d_aux are per (row, step): two fp32 forwards differ by ~1e-7 in the fc1 / fc2 pre-activations, so a ReLU unit that sits
+    # within that of zero takes the other branch in one of them, and that (row, step) -- plus the few steps before it, through the GRU
+    # carries -- gets a visibly different gradient (with the "peaky" fc3 x 8 weights: up to 5e-2 of the largest entry).  Measured with
+    # tools/diag_team_batches.py (profiles/r03_team_vs_steps_diag.txt): B = 70: 20 of 38 500 (row, step) pairs in 2 rows, none of them in
+    # the team's second batch; float64 autograd disagrees with BOTH fp32 variants in the same way (B = 61: the same 28 pairs in either).
+    # So: everything else equal to 1e-5, and at most 0.2 % of the pairs touched by a flip.
+    for ga, gb, k in [(a[3], b[3], 'd_mels_up'), (a[4], b[4], 'd_aux')]:
+        e = np.abs(ga - gb).max(axis=2) / max(np.abs(ga).max(), 1e-12)            # (row, step)
+        flipped = int((e > 1e-4).sum())
+        assert float(np.quantile(e, 0.99)) <= 1e-5 and flipped <= 0.002 * e.size, (k, float(np.quantile(e, 0.99)), flipped, e.size)
     print(f'\n[train] team vs step recurrence kernels, B={B}: worst gradient difference {worst:.2e} of the largest entry')
 
 
