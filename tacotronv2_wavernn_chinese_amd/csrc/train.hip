@@ -39,6 +39,10 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #define GT_N 128
 #define GT_K 16
 #define GT_LD (GT_M + 4)
+#ifndef TN_WG_TARGET
+#define TN_WG_TARGET 768   // workgroups a split-K weight-gradient GEMM aims for (slices x tiles): 3 per CU = the kernel's occupancy
+                           // (measured per iteration: 256 -> 26.5 ms, 512 -> 25.5, 768 -> 25.3, 1024 -> 26.4)
+#endif
 
 // A(m,k) = TA ? A[k*lda + m] : A[m*lda + k];  B(k,n) = TB ? B[n*ldb + k] : B[k*ldb + n]
 template <bool TA, bool TB>
@@ -795,9 +799,9 @@ static int train_impl(wrnn_handle *h, int phase, const wrnn_loop_params *w, cons
     // the chip, partial products summed in slice order (deterministic)
     auto gemm_tn = [&](const float *Am, long lda, const float *Bm, long ldb, float *Cm, long ldc, int Mo, int No) -> hipError_t {
         const int tiles = ((Mo + GT_M - 1) / GT_M) * ((No + GT_N - 1) / GT_N);
-        // slices x tiles <= 256 workgroups = one pass over the chip's CUs (with ceil() 48 tiles x 6 slices = 288 workgroups ran as one
-        // full pass + a 12 % second one: 0.56 of the machine)
-        int S = tiles >= 128 ? 1 : 256 / tiles;
+        // slices x tiles <= TN_WG_TARGET workgroups, all co-resident (with ceil() 48 tiles x 6 slices = 288 workgroups ran as one full pass
+        // over 256 CUs + a 12 % second one)
+        int S = tiles >= TN_WG_TARGET / 2 ? 1 : TN_WG_TARGET / tiles;
         if (S > 64) S = 64;
         while (S > 1 && (size_t)S * Mo * No > sk_floats) --S;
         if (S <= 1) return gemm(s, true, false, Am, lda, Bm, ldb, Cm, ldc, Mo, No, (int)M);

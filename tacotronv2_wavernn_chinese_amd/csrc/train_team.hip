@@ -17,6 +17,18 @@
 //             4 rows x 64 outputs x one k.  2 barriers per step.
 #include "batch_common.h"
 
+// developer build (-DTT_PROF): cycles per phase of a step, summed over the launch by thread 0 of workgroup 0 of team 0, printed at the end
+#ifdef TT_PROF
+#define TP_DECL unsigned long long tp_last = __builtin_readcyclecounter(), tp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); tp_acc[i] += n_ - tp_last; tp_last = n_; } while (0)
+#define TP_PRINT(name, steps) do { if (team == 0 && g == 0 && tid == 0) printf("%s: cycles per step:  %llu %llu %llu %llu %llu %llu %llu %llu\n", name, \
+    tp_acc[0] / (steps), tp_acc[1] / (steps), tp_acc[2] / (steps), tp_acc[3] / (steps), tp_acc[4] / (steps), tp_acc[5] / (steps), tp_acc[6] / (steps), tp_acc[7] / (steps)); } while (0)
+#else
+#define TP_DECL
+#define TP(i)
+#define TP_PRINT(name, steps)
+#endif
+
 namespace {
 
 constexpr int TT_H = 512;
@@ -91,18 +103,28 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_fwd_kernel(WrnnGruTeamArg
     const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)F::L_H * 4u + ((unsigned)(tid >> 5) * 256u + 2u * (unsigned)(tid & 31)) * 4u);
     bool dead = false;
     unsigned epoch = 0;
+    TP_DECL;
     for (int batch = team; batch < n_batches; batch += a.n_teams) {
         const int brow = batch * a.rpb + rb;
         const bool row_ok = primary && rb < a.rpb && brow < a.B;
         const size_t rbase = (size_t)(row_ok ? brow : 0) * a.L;
         for (int i = tid; i < F::VEC; i += TB_THREADS) lds[F::L_H + i] = 0.0f;   // h_{-1} = 0 (:141-142)
         float hprev = 0.0f;
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
-        if (row_ok) { const float *gi = a.GI + rbase * G3 + unit; gi_r = gi[0]; gi_z = gi[H]; gi_n = gi[2 * H]; }
+        // the input parts of steps t (ga) and t + 1 (gb): a step consumes its set at the gates and refills it for step t + 2 right BEHIND
+        // its gather, so the loads never sit in front of a poll (vmcnt retires in order: a poll issued behind an HBM load waits for it too)
+        // and have two steps to land; the loop is unrolled by two so that the sets rotate by name, not by copies (a copy of a register that
+        // is being loaded is a wait for the load)
+        float ga[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
+        if (row_ok) {
+            const float *gi = a.GI + rbase * G3 + unit;
+            ga[0] = gi[0]; ga[1] = gi[H]; ga[2] = gi[2 * H];
+            if (a.L > 1) { gb[0] = gi[G3]; gb[1] = gi[G3 + H]; gb[2] = gi[G3 + 2 * H]; }
+        }
         __syncthreads();
-        for (int64_t t = 0; t < a.L; ++t) {
+        auto step = [&](const int64_t t, float (&gv)[3]) __attribute__((always_inline)) {
             ++epoch;
             const unsigned par = epoch & 1u;
+            TP(7);
             f4 acc[3][NQ];
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt)
@@ -122,6 +144,7 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_fwd_kernel(WrnnGruTeamArg
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[gt][q] = mfma4(w[gt][e], b[q][e], acc[gt][q]);
             }
+            TP(0);   // MFMA phase
             float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -129,31 +152,64 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_fwd_kernel(WrnnGruTeamArg
                 if (q == 0 || my_rq == q) { tr = fr; tz = fz; tn = fn; }
             }
             const float ghr = tr + bh_r, ghz = tz + bh_z, ghn = tn + bh_n;
-            const float r = 1.0f / (1.0f + expf(-(gi_r + ghr))), z = 1.0f / (1.0f + expf(-(gi_z + ghz)));
-            const float n = tanhf(gi_n + r * ghn);
+            const float r = 1.0f / (1.0f + expf(-(gv[0] + ghr))), z = 1.0f / (1.0f + expf(-(gv[1] + ghz)));
+            const float n = tanhf(gv[2] + r * ghn);
             const float h = (1.0f - z) * n + z * hprev;
+            TP(1);   // folds + gates
             if (primary) st_granule(mail, par * F::RG + mb_own, epoch, __float_as_uint(h));
+            hprev = h;
+            // the step's results go out between the publish and the first look (stores are acknowledged by the L2, they do not hold
+            // the poll up like a load from HBM would)
             if (row_ok) {
                 const size_t o = (rbase + t) * H + unit;
                 a.Hs[o] = h; a.Rs[o] = r; a.Zs[o] = z; a.Ns[o] = n; a.GHN[o] = ghn;
-                if (t + 1 < a.L) {
-                    a.HP[o + H] = h;
-                    const float *gi = a.GI + (rbase + t + 1) * G3 + unit;   // next step's input part: lands under the exchange
-                    gi_r = gi[0]; gi_z = gi[H]; gi_n = gi[2 * H];
-                }
+                if (t + 1 < a.L) a.HP[o + H] = h;
             }
-            hprev = h;
+            TP(2);   // publish + stores
             {   // also after the LAST step, whose result nobody needs: the gather is what keeps the 32 workgroups within one publish
                 // of each other -- without it a fast workgroup starts the team's next batch and overwrites the parity region a slow one
                 // is still reading for step L - 2 (found with B = 70: 9 batches on 8 teams)
-                u4v gx[1][NM];
-                const unsigned offs[1] = {par * F::RG * 8u};
-                gather_vecs<NM, 1>(mrs, gvoff, offs, epoch, gx, dead, a.err, 31u);
+                const unsigned so = par * F::RG * 8u;
+                u4v gx[NM];
+                unsigned spins = 0;
+                for (;;) {   // SENTINEL FIRST: one slice per lane until it carries this step's tag, then everything once.  A full look that
+                             // comes back stale is R x 4 KB of L2 reads per workgroup for nothing, and the publishes of the other workgroups
+                             // queue behind those reads: with the full look first a gather took 2.6-3.0 k cycles, like this 1.3 k
+                    const u4v sv = ld_pair(mrs, gvoff, so + (NM - 1) * 4096u);
+                    if (__all(sv.y == epoch && sv.w == epoch) || dead) break;
+                    if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 31u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
 #pragma unroll
-                for (int m = 0; m < NM; ++m) gdst[((m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
-                __syncthreads();
+                for (int m = 0; m < NM; ++m) gx[m] = ld_pair(mrs, gvoff, so + m * 4096u);
+                for (;;) {   // per-granule retry: only what came back stale is looked at again
+                    bool ok = true;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) ok = ok && gx[m].y == epoch && gx[m].w == epoch;
+                    if (__all(ok) || dead) break;
+                    if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 31u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m)
+                        if (!(gx[m].y == epoch && gx[m].w == epoch)) gx[m] = ld_pair(mrs, gvoff, so + m * 4096u);
+                }
+                TP(3);   // gather
+#pragma unroll
+                for (int m = 0; m < NM; ++m) gdst[((m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[m].x), __uint_as_float(gx[m].z)};
             }
-            if ((t & 63) == 63) {
+            if (row_ok && t + 2 < a.L) {   // refill the consumed set for step t + 2: behind the poll, never in front of it (measured: in front,
+                                           // the HBM round trip of ~1 500 cycles holds the first look up: 1.29 -> 1.90 k cycles per gather)
+                const float *gi = a.GI + (rbase + t + 2) * G3 + unit;
+                gv[0] = gi[0]; gv[1] = gi[H]; gv[2] = gi[2 * H];
+            }
+            TP(4);   // LDS write + loads issued
+            __syncthreads();
+            TP(5);   // barrier
+        };
+        for (int64_t t = 0; t < a.L; t += 2) {
+            step(t, ga);
+            if (t + 1 < a.L) step(t + 1, gb);
+            if ((t & 62) == 62) {
                 if (dead && lane == 0) misc_i[M_DEAD] = 1;
                 __syncthreads();
                 if (misc_i[M_DEAD]) return;
@@ -161,6 +217,7 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_fwd_kernel(WrnnGruTeamArg
         }
         __syncthreads();
     }
+    TP_PRINT("gru_team_fwd", (unsigned long long)a.L);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward
@@ -209,23 +266,29 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
     const lds_cf4p wim = (lds_cf4p)(size_t)launder(smem_base + (unsigned)Bk::L_W * 4u + (unsigned)lane * 16u);
     bool dead = false;
     unsigned epoch = 0;
+    TP_DECL;
     for (int batch = team; batch < n_batches; batch += a.n_teams) {
         const int brow = batch * a.rpb + prow;
         const bool row_ok = pair && prow < a.rpb && brow < a.B;
         const size_t rbase = (size_t)(row_ok ? brow : 0) * a.L;
         float carry = 0.0f, cd = 0.0f;
-        float e_dh = 0.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_ghn = 0.f, e_hp = 0.f;
+        // saved activations {dHext, r, z, n, gh_n, h_prev} of steps t (ea) and t - 1 (eb): consumed by the gate derivatives at the top of
+        // a step and refilled for step t - 2 BEHIND the step's poll (see the forward kernel); unrolled by two, the sets rotate by name
+        float ea[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, eb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (row_ok) {
             const size_t o = (rbase + a.L - 1) * H + punit;
-            e_dh = a.dHext[o]; e_r = a.Rs[o]; e_z = a.Zs[o]; e_n = a.Ns[o]; e_ghn = a.GHN[o]; e_hp = a.HP[o];
+            ea[0] = a.dHext[o]; ea[1] = a.Rs[o]; ea[2] = a.Zs[o]; ea[3] = a.Ns[o]; ea[4] = a.GHN[o]; ea[5] = a.HP[o];
+            if (a.L > 1) { const size_t o2 = o - H; eb[0] = a.dHext[o2]; eb[1] = a.Rs[o2]; eb[2] = a.Zs[o2]; eb[3] = a.Ns[o2]; eb[4] = a.GHN[o2]; eb[5] = a.HP[o2]; }
         }
-        for (int64_t t = a.L - 1; t >= 0; --t) {
+        auto step = [&](const int64_t t, float (&ev)[6]) __attribute__((always_inline)) {
             ++epoch;
             const unsigned par = epoch & 1u;
+            TP(7);
             // ---- gate derivatives of the own (unit, row) pairs (see gru_bwd_step_kernel, train.hip)
+            float dpr = 0.f, dpz = 0.f, dpn = 0.f, dghn = 0.f;
             if (pair) {
-                float dpr = 0.f, dpz = 0.f, dpn = 0.f, dghn = 0.f;
                 if (row_ok) {
+                    const float e_dh = ev[0], e_r = ev[1], e_z = ev[2], e_n = ev[3], e_ghn = ev[4], e_hp = ev[5];
                     const float dH = e_dh + carry + cd;
                     const float dn = dH * (1.0f - e_z), dz = dH * (e_hp - e_n);
                     dpn = dn * (1.0f - e_n * e_n);
@@ -233,17 +296,12 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
                     dpz = dz * e_z * (1.0f - e_z);
                     dghn = dpn * e_r;
                     cd = dH * e_z;
-                    const size_t o = (rbase + t) * G3 + punit;
-                    a.dGI[o] = dpr; a.dGI[o + H] = dpz; a.dGI[o + 2 * H] = dpn;
-                    a.dGH[o] = dpr; a.dGH[o + H] = dpz; a.dGH[o + 2 * H] = dghn;
-                    if (t > 0) {   // next step's inputs: the loads fly under the MFMAs and the exchange
-                        const size_t o2 = (rbase + t - 1) * H + punit;
-                        e_dh = a.dHext[o2]; e_r = a.Rs[o2]; e_z = a.Zs[o2]; e_n = a.Ns[o2]; e_ghn = a.GHN[o2]; e_hp = a.HP[o2];
-                    }
                 }
                 Gs[prow * 48 + pu] = dpr; Gs[prow * 48 + 16 + pu] = dpz; Gs[prow * 48 + 32 + pu] = dghn;
             }
+            TP(0);   // gate derivatives, stores
             __syncthreads();   // (t == 0 included: its carry is not needed, its exchange keeps the team in lock-step across batches)
+            TP(1);   // barrier
             // ---- partial carry of ALL 512 units from the own 48 gate rows: P[row][out] = sum_k G[row][k] W[k][out]
             f4 acc[2][NQ];
 #pragma unroll
@@ -264,6 +322,7 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[cc][q] = mfma4(ga[q][kk], wb[cc][kk], acc[cc][q]);
             }
+            TP(2);   // MFMA phase
             // ---- publish: D[i] of lane (blk, j) = P[row 4 q + i][out = 64 c + 4 blk + j] -> owner workgroup out >> 4
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
@@ -275,14 +334,27 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
                     for (int i = 0; i < 4; ++i)
                         st_granule(mail, base + (unsigned)(4 * q + i) * 512u, epoch, __float_as_uint(acc[cc][q][i]));
             }
+            // ---- behind the publish, in front of the first look: this step's results out (stores are acknowledged by the L2)
+            if (row_ok) {
+                const size_t o = (rbase + t) * G3 + punit;
+                a.dGI[o] = dpr; a.dGI[o + H] = dpz; a.dGI[o + 2 * H] = dpn;
+                a.dGH[o] = dpr; a.dGH[o + H] = dpz; a.dGH[o + 2 * H] = dghn;
+            }
+            TP(3);   // publish, stores
             // ---- reduce-scatter: the partials of the own units from all 32 workgroups
             {
                 const unsigned voff = (((unsigned)crow * 32u) * 16u + 2u * (unsigned)cup) * 8u;
                 const unsigned soff = (par * Bk::RG + (unsigned)g * (unsigned)(R * 512)) * 8u;
                 u4v gq[NSRC];
+                unsigned spins = 0;
+                for (;;) {   // sentinel first (see the forward kernel)
+                    const u4v sv = ld_pair(mrs, voff + (unsigned)(csrc0 + NSRC - 1) * 128u, soff);
+                    if (__all(sv.y == epoch && sv.w == epoch) || dead) break;
+                    if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 32u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
 #pragma unroll
                 for (int m = 0; m < NSRC; ++m) gq[m] = ld_pair(mrs, voff + (unsigned)(csrc0 + m) * 128u, soff);
-                unsigned spins = 0;
                 for (;;) {
                     bool ok = true;
 #pragma unroll
@@ -302,7 +374,13 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
                 red[(grp * R + crow) * 16 + 2 * cup] = s0;
                 red[(grp * R + crow) * 16 + 2 * cup + 1] = s1;
             }
+            TP(4);   // reduce-scatter poll + partial sums
+            if (row_ok && t > 1) {   // the inputs of step t - 2: behind the poll
+                const size_t o2 = (rbase + t - 2) * H + punit;
+                ev[0] = a.dHext[o2]; ev[1] = a.Rs[o2]; ev[2] = a.Zs[o2]; ev[3] = a.Ns[o2]; ev[4] = a.GHN[o2]; ev[5] = a.HP[o2];
+            }
             __syncthreads();
+            TP(5);   // loads issued + barrier
             if (pair) {
                 constexpr int NG = NQ == 2 ? 4 : 8;
                 float acc_c = 0.0f;
@@ -310,7 +388,11 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
                 for (int gq2 = 0; gq2 < NG; ++gq2) acc_c += red[(gq2 * R + prow) * 16 + pu];
                 carry = acc_c;
             }
-            if ((epoch & 63u) == 63u) {
+        };
+        for (int64_t t = a.L - 1; t >= 0; t -= 2) {
+            step(t, ea);
+            if (t >= 1) step(t - 1, eb);
+            if ((epoch & 62u) == 62u) {
                 if (dead && lane == 0) misc_i[M_DEAD] = 1;
                 __syncthreads();
                 if (misc_i[M_DEAD]) return;
@@ -318,6 +400,7 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
         }
         __syncthreads();
     }
+    TP_PRINT("gru_team_bwd", (unsigned long long)a.L);
 }
 
 // ---- weight images (device-side repack; the parameters change every optimiser step) -----------------------------------------------
