@@ -138,6 +138,14 @@ __device__ __forceinline__ void gather_issue(__amdgpu_buffer_rsrc_t rs, unsigned
         for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, voff, soff[v] + m * 4096u);
     __builtin_amdgcn_sched_barrier(0);
 }
+// developer build (-DWRNN_COUNT_SLOW): how often an exchange's first look comes back stale (workgroup 0, wave 0; printed by the kernel)
+#ifdef WRNN_COUNT_SLOW
+__device__ unsigned wrnn_dbg_slow[64];
+#define WRNN_SLOW_NOTE(code, slow) do { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&wrnn_dbg_slow[32 + ((code) & 31)], 1u); \
+    if (slow) atomicAdd(&wrnn_dbg_slow[(code) & 31], 1u); } } while (0)
+#else
+#define WRNN_SLOW_NOTE(code, slow)
+#endif
 template <int NM, int NV, bool PRE = false>
 __device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, unsigned voff, const unsigned (&soff)[NV], unsigned tag, u4v (&g)[NV][NM],
                                             bool &dead, unsigned *err, unsigned code) {
@@ -148,14 +156,22 @@ __device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, unsigned 
             for (int m = 0; m < NM; ++m) g[v][m] = ld_pair(rs, voff, soff[v] + m * 4096u);
     }
     unsigned spins = 0;
+#ifdef WRNN_COUNT_SLOW
+    bool first_ = true;
+#endif
     for (;;) {
         bool ok = true;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int m = 0; m < NM; ++m) ok = ok && g[v][m].y == tag && g[v][m].w == tag;
+#ifdef WRNN_COUNT_SLOW
+        if (first_) { WRNN_SLOW_NOTE(code, !__all(ok)); first_ = false; }
+#endif
         if (__all(ok) || dead) break;
         // wait on the sentinel slice of the last vector, then look at everything again
+        // (three sentinel loads in flight instead of one -- the arrival noticed a third of a round trip after it happened -- measured
+        //  +0.2 % at R = 4, -0.7 % at R = 8, nothing in the training kernels: more polls are more L2 traffic; not kept)
         for (;;) {
             if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
             __builtin_amdgcn_s_sleep(1);
@@ -177,8 +193,8 @@ __device__ __forceinline__ void gather_vecs(__amdgpu_buffer_rsrc_t rs, unsigned 
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
 
 // acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane];
-// mid() runs before slab 4 (the early request of the next exchange's granules)
-template <int NQ, int NG, bool AG, int D, class F>
+// mid() runs before slab MS (the early request of the next exchange's granules)
+template <int NQ, int NG, bool AG, int D, class F, int MS = 4>
 __device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc)[NG][NQ], F mid) {
     f4 ring[D][NQ];
 #pragma unroll
@@ -187,7 +203,7 @@ __device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc
         for (int q = 0; q < NQ; ++q) ring[dd][q] = xv[(q * 8 + dd) * 64];
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
-        if (S == 4) mid();
+        if (S == MS) mid();
         f4 b[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) b[q] = ring[S % D][q];

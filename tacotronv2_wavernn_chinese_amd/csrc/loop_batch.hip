@@ -350,9 +350,14 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                     for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u};
-                // the x3 slices are requested half way through the shadow MFMAs (the producers are normally done by then), so
-                // their L2 round trip runs under the second half instead of after it
-                mfma_gates<NQ, 3, true, DG>(wa, vH1, acc, [&]() { gather_issue<NM, 1>(mrs, gvoff, offs, gx); });
+                // the x3 slices are requested part of the way through the shadow MFMAs (the producers are normally done by then), so their
+                // L2 round trip runs under the rest instead of after it.  R = 8: half way.  R = 4: before the LAST slab -- the phase is half
+                // as long, and requested half way 36 % of the early looks came back stale (counted with -DWRNN_COUNT_SLOW) and took the
+                // slow path: sentinel polls + a second full look (MOL B = 32: 5 120 -> 5 280 ksamples/s, A/B in one session)
+                {
+                    auto req = [&]() { gather_issue<NM, 1>(mrs, gvoff, offs, gx); };
+                    mfma_gates<NQ, 3, true, DG, decltype(req), (NQ == 1 ? 7 : 4)>(wa, vH1, acc, req);
+                }
                 PB(7);   // W_hh1 MFMAs issued
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -646,6 +651,11 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
         }
         __syncthreads();
     }
+#ifdef WRNN_COUNT_SLOW
+    if (blockIdx.x == 0 && tid == 0)
+        printf("stale first looks / looks: x2 %u/%u  h1 %u/%u  x3 %u/%u  f1 %u/%u  f2 %u/%u\n", wrnn_dbg_slow[21], wrnn_dbg_slow[53], wrnn_dbg_slow[22],
+               wrnn_dbg_slow[54], wrnn_dbg_slow[23], wrnn_dbg_slow[55], wrnn_dbg_slow[24], wrnn_dbg_slow[56], wrnn_dbg_slow[25], wrnn_dbg_slow[57]);
+#endif
     if (PROF && a.prof && lane == 0 && g == 0 && team == 0) {
         for (int i = 0; i < 24; ++i) a.prof[wl * WRNN_PROF_SLOTS + i] += prof_lds[wl * 24 + i];
     }

@@ -172,9 +172,10 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_fwd_kernel(WrnnGruTeamArg
                 const unsigned so = par * F::RG * 8u;
                 u4v gx[NM];
                 unsigned spins = 0;
-                for (;;) {   // SENTINEL FIRST: one slice per lane until it carries this step's tag, then everything once.  A full look that
-                             // comes back stale is R x 4 KB of L2 reads per workgroup for nothing, and the publishes of the other workgroups
-                             // queue behind those reads: with the full look first a gather took 2.6-3.0 k cycles, like this 1.3 k
+                // SENTINEL FIRST: one slice per lane until it carries this step's tag, then everything once.  A full look that comes back
+                // stale is R x 4 KB of L2 reads per workgroup for nothing, and the publishes of the other workgroups queue behind those
+                // reads: with the full look first a gather took 2.6-3.0 k cycles, like this 1.3 k
+                for (;;) {
                     const u4v sv = ld_pair(mrs, gvoff, so + (NM - 1) * 4096u);
                     if (__all(sv.y == epoch && sv.w == epoch) || dead) break;
                     if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 31u); break; }
@@ -347,7 +348,8 @@ __global__ void __launch_bounds__(TB_THREADS) gru_team_bwd_kernel(WrnnGruTeamArg
                 const unsigned soff = (par * Bk::RG + (unsigned)g * (unsigned)(R * 512)) * 8u;
                 u4v gq[NSRC];
                 unsigned spins = 0;
-                for (;;) {   // sentinel first (see the forward kernel)
+                // sentinel first (see the forward kernel)
+                for (;;) {
                     const u4v sv = ld_pair(mrs, voff + (unsigned)(csrc0 + NSRC - 1) * 128u, soff);
                     if (__all(sv.y == epoch && sv.w == epoch) || dead) break;
                     if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 32u); break; }
