@@ -228,25 +228,27 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 nz0 = cls0 < NC ? -logf(qp[cls0]) : 0.0f;
                 nz1 = cls0 + 4 < NC ? -logf(qp[cls0 + 4]) : 0.0f;
             } else if (a.noise_mode == WRNN_NOISE_PHILOX) {
-                // one Philox block = classes (2c, 2c+1) x steps (2s, 2s+1) (device_util.h): evaluated on even steps, the odd
-                // step's draws are kept.  Lane l (units 0, 2 of the wave: even classes c, c+4) and lane l+32 (units 1, 3:
-                // classes c+1, c+5) need the same two blocks: the lower lane evaluates block(c), the upper one block(c+4),
-                // and each hands the partner its half with one v_permlane32_swap per step parity.
-                // -log q = -log(-log u): the inner log exactly (q is tiny for u -> 1, where v_log_f32 is not accurate
-                // relative to the result and such a draw tends to win the race), the outer one fast.
+                // one Philox block = classes (2c, 2c+1) x steps (2s, 2s+1) (device_util.h): evaluated on even steps.  Lane l (units 0, 2 of
+                // the wave: even classes c, c+4) and lane l+32 (units 1, 3: classes c+1, c+5) need the same two blocks: the lower lane
+                // evaluates block(c), the upper one block(c+4), and each hands the partner its half with one v_permlane32_swap.
+                // -log q = -log(-log u): the inner log exactly (q is tiny for u -> 1, where v_log_f32 is not accurate relative to the
+                // result and such a draw tends to win the race), the outer one fast.
+                // The block on even steps, its two halves TRANSFORMED one per step (pz0 / pz1 carry the odd step's raw bits).  The first
+                // version transformed all four draws on the even step: ~2 000 cycles there -- more than the f2 exchange this sits under
+                // hides -- and nothing on the odd one.  Same values, the work spread evenly: B = 64 6 624 -> 6 824 ksamples/s, and the
+                // kernel's 12 bytes of scratch are gone.
+                const bool upper = lane >= 32;
+                unsigned ba, bb;
                 if ((ts & 1) == 0) {
-                    const bool upper = lane >= 32;
                     const Philox4 pb = wrnn_raw_block(a.seed, (uint64_t)ts, (uint32_t)row, (uint32_t)(upper ? cls0 + 4 : cls0));
-                    const float ge = -__logf(-logf(u01_from_bits(pb.x))), go = -__logf(-logf(u01_from_bits(pb.y)));   // even step: class 2c | 2c+1
-                    const float he = -__logf(-logf(u01_from_bits(pb.z))), ho = -__logf(-logf(u01_from_bits(pb.w)));   // odd step
-                    const float mine_e = upper ? go : ge, give_e = upper ? ge : go;
-                    const float mine_o = upper ? ho : he, give_o = upper ? he : ho;
-                    const u2v se = __builtin_amdgcn_permlane32_swap(__float_as_uint(give_e), __float_as_uint(give_e), false, false);
-                    const u2v so = __builtin_amdgcn_permlane32_swap(__float_as_uint(give_o), __float_as_uint(give_o), false, false);
-                    const float recv_e = __uint_as_float(upper ? se.x : se.y), recv_o = __uint_as_float(upper ? so.x : so.y);
-                    nz0 = upper ? recv_e : mine_e; nz1 = upper ? mine_e : recv_e;
-                    pz0 = upper ? recv_o : mine_o; pz1 = upper ? mine_o : recv_o;
-                } else { nz0 = pz0; nz1 = pz1; }
+                    ba = pb.x; bb = pb.y;
+                    pz0 = __uint_as_float(pb.z); pz1 = __uint_as_float(pb.w);
+                } else { ba = __float_as_uint(pz0); bb = __float_as_uint(pz1); }
+                const float ge = -__logf(-logf(u01_from_bits(ba))), go = -__logf(-logf(u01_from_bits(bb)));
+                const float mine_e = upper ? go : ge, give_e = upper ? ge : go;
+                const u2v se = __builtin_amdgcn_permlane32_swap(__float_as_uint(give_e), __float_as_uint(give_e), false, false);
+                const float recv_e = __uint_as_float(upper ? se.x : se.y);
+                nz0 = upper ? recv_e : mine_e; nz1 = upper ? mine_e : recv_e;
             } else { nz0 = 0.f; nz1 = 0.f; }
         };
         cond_fetch(0);
