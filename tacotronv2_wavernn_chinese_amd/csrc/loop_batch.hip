@@ -353,12 +353,13 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 u4v gx[1][NM];
                 const unsigned offs[1] = {(L::G_X3 + par * L::RG) * 8u};
                 // the x3 slices are requested part of the way through the shadow MFMAs (the producers are normally done by then), so their
-                // L2 round trip runs under the rest instead of after it.  R = 8: half way.  R = 4: before the LAST slab -- the phase is half
+                // L2 round trip runs under the rest instead of after it.  R = 8: before slab 5 of 8 (3: -1.7 %, stale looks; 4: -0.7 %; 6, 7:
+                // -0.3 %; the same for the fc1 slices in window 3).  R = 4: before the LAST slab -- the phase is half
                 // as long, and requested half way 36 % of the early looks came back stale (counted with -DWRNN_COUNT_SLOW) and took the
                 // slow path: sentinel polls + a second full look (MOL B = 32: 5 120 -> 5 280 ksamples/s, A/B in one session)
                 {
                     auto req = [&]() { gather_issue<NM, 1>(mrs, gvoff, offs, gx); };
-                    mfma_gates<NQ, 3, true, DG, decltype(req), (NQ == 1 ? 7 : 4)>(wa, vH1, acc, req);
+                    mfma_gates<NQ, 3, true, DG, decltype(req), (NQ == 1 ? 7 : 5)>(wa, vH1, acc, req);
                 }
                 PB(7);   // W_hh1 MFMAs issued
 #pragma unroll
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(TB_THREADS) loop_batch_kernel(WrnnBatchArgs a)
                 for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
 #pragma unroll
                 for (int S = 0; S < 8; ++S) {
-                    if (S == 4) gather_issue<NM, 1>(mrs, gvoff, offs, gx);   // fc1 slices requested half way (see window 2)
+                    if (S == (NQ == 1 ? 4 : 5)) gather_issue<NM, 1>(mrs, gvoff, offs, gx);   // fc1 slices requested part of the way (see window 2)
                     f4 b[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];

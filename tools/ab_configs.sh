@@ -2,7 +2,7 @@
 # A/B of library builds on bench configs in ONE GPU session:  tools/ab_configs.sh "2 4" libA.so libB.so ...   ("product" = the shipped one)
 cd "$(dirname "$0")/.." || exit 1
 cfgs=$1; shift
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
   for c in $cfgs; do
     for lib in "$@"; do
       if [ "$lib" = product ]; then cmd="python bench.py"; else cmd="python tools/ab_bench.py $lib"; fi
