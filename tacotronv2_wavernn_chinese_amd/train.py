@@ -126,43 +126,52 @@ def voc_train_loop(paths: VocPaths, model, loss_func: Optional[Callable], optimi
     params = [p for p in model.parameters() if p.requires_grad]
     losses = []
     model.train()
-    for epoch in range(1, epochs + 1):
-        t0 = time.time()
-        running = 0.0
-        msg = ''
-        for i, (x, y, m) in enumerate(train_set, 1):
-            x, m, y = x.to(device), m.to(device), y.to(device)
-            if loss_func is None:
-                loss = model.training_loss(x, m, y)
-            else:
-                y_hat = model(x, m)
-                if model.mode == 'RAW':
-                    y_hat = y_hat.transpose(1, 2).unsqueeze(-1)
+    # Device-side errors of the training kernels are asked for once per iteration (at the loss.item() below, where the host waits anyway)
+    # instead of inside every call, and the NaN message of the clipping waits for the same point: the host queues the upsample network's
+    # backward, the clipping and Adam while the step is still running.  An error raises before the iteration's weights can reach a
+    # checkpoint.
+    check_mode, model.check_device_errors = getattr(model, 'check_device_errors', True), 'deferred'
+    try:
+        for epoch in range(1, epochs + 1):
+            t0 = time.time()
+            running = 0.0
+            msg = ''
+            for i, (x, y, m) in enumerate(train_set, 1):
+                x, m, y = x.to(device), m.to(device), y.to(device)
+                if loss_func is None:
+                    loss = model.training_loss(x, m, y)
                 else:
-                    y = y.float()
-                loss = loss_func(y_hat, y.unsqueeze(-1))
-            optimizer.zero_grad()
-            loss.backward()
-            if clip_grad_norm is not None:
-                norm = torch.nn.utils.clip_grad_norm_(params, clip_grad_norm)
-                if not bool(torch.isfinite(norm)):
+                    y_hat = model(x, m)
+                    if model.mode == 'RAW':
+                        y_hat = y_hat.transpose(1, 2).unsqueeze(-1)
+                    else:
+                        y = y.float()
+                    loss = loss_func(y_hat, y.unsqueeze(-1))
+                optimizer.zero_grad()
+                loss.backward()
+                norm = torch.nn.utils.clip_grad_norm_(params, clip_grad_norm) if clip_grad_norm is not None else None
+                optimizer.step()
+                value = loss.item()                  # the one host sync of an iteration (the reference has it too, :129)
+                if hasattr(model, 'training_status'):
+                    model.training_status()
+                if norm is not None and not bool(torch.isfinite(norm)):
                     print('grad_norm was NaN!')
-            optimizer.step()
-            value = loss.item()                      # the one host sync of an iteration (the reference has it too, :129)
-            losses.append(value)
-            running += value
-            step = model.get_step()
-            if step % checkpoint_every == 0:
-                if at_checkpoint is not None:
-                    at_checkpoint(model, test_set, step)
-                    model.train()
-                save_checkpoint(paths, model, optimizer, name=f'wave_step{step // 1000}K')
-            msg = (f'| Epoch: {epoch}/{epochs} ({i}/{per_epoch}) | Loss: {running / i:.4f} | '
-                   f'{i / (time.time() - t0):.1f} steps/s | Step: {step // 1000}k | ')
-            if report is not None:
-                report(msg)
-        save_checkpoint(paths, model, optimizer)     # the optimizer state of the epoch's end, so resuming does not jump (:147-149)
-        model.log(paths.voc_log, msg)
+                losses.append(value)
+                running += value
+                step = model.get_step()
+                if step % checkpoint_every == 0:
+                    if at_checkpoint is not None:
+                        at_checkpoint(model, test_set, step)
+                        model.train()
+                    save_checkpoint(paths, model, optimizer, name=f'wave_step{step // 1000}K')
+                msg = (f'| Epoch: {epoch}/{epochs} ({i}/{per_epoch}) | Loss: {running / i:.4f} | '
+                       f'{i / (time.time() - t0):.1f} steps/s | Step: {step // 1000}k | ')
+                if report is not None:
+                    report(msg)
+            save_checkpoint(paths, model, optimizer)     # the optimizer state of the epoch's end, so resuming does not jump (:147-149)
+            model.log(paths.voc_log, msg)
+    finally:
+        model.check_device_errors = check_mode
     return losses
 
 

@@ -113,7 +113,11 @@ class WaveRNN(nn.Module):
         self._native_key = None
         # knobs that are not part of the reference signature
         self.kernel = _cabi.KERNEL_AUTO
-        self.check_device_errors = True   # training_loss waits for its kernels and raises on a device-side error
+        # True: every training call (training_loss, forward / backward in train() mode) waits for its kernels and raises on a device-side
+        # error (a busy GPU, a timed-out team kernel) -- safe, but the host cannot queue the rest of the iteration (the upsample network's
+        # backward, clipping, Adam: ~150 small launches) under the running step.  'deferred': no wait; the caller asks once per iteration
+        # with ``training_status()`` (``train.voc_train_loop`` does, at its ``loss.item()``, and before it writes a checkpoint).
+        self.check_device_errors = True
         self.verbose = True
         self.last_timing: Optional[dict] = None
 
@@ -255,8 +259,31 @@ class WaveRNN(nn.Module):
             raise ValueError(f'expected x, y (B, {max(T, 0) * self.hop_length}) for mels {tuple(mels.shape)}')
         self.step += 1
         mels_up, aux = self.upsample_torch(mels)
+        if not torch.is_grad_enabled():   # a validation pass: forward + loss only (wrnn_train_step without gradient outputs)
+            mels_up, aux = mels_up.contiguous(), aux.contiguous()
+            nat = self._native_handle()
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            logits = torch.empty((x.size(0), x.size(1), self.n_classes), dtype=torch.float32, device=dev) if return_logits else None
+            ps = [p.detach().contiguous() for p in self._loop_params()]
+            with torch.cuda.device(dev):
+                st = torch.cuda.current_stream(dev).cuda_stream
+                nat.train_step([p.data_ptr() for p in ps], None, x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(), y.data_ptr(), x.size(0), x.size(1),
+                               loss.data_ptr(), logits.data_ptr() if return_logits else 0, 0, 0, st)
+                if self.check_device_errors is True:
+                    nat.sync_status(st)
+            return (loss, logits) if return_logits else loss
         out = _LoopTrainFn.apply(self, x, y, return_logits, mels_up.contiguous(), aux.contiguous(), *self._loop_params())
         return out if return_logits else out[0]
+
+    def training_status(self):
+        """Waits for the model's stream and raises ``WrnnError`` if a training kernel launched since the last forward pass reported a
+        device-side error (``wrnn_sync_status``).  For ``check_device_errors = 'deferred'``: call it once per iteration, before the weights
+        of that iteration are trusted (written to a checkpoint)."""
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda' or self._native is None:
+            return
+        with torch.cuda.device(dev):
+            self._native.sync_status(torch.cuda.current_stream(dev).cuda_stream)
 
     # ---------------------------------------------------------------- generate
     def generate_raw(self, mels, batched, target, overlap, *, noise_mode=_cabi.NOISE_PHILOX, seed=0,
@@ -517,7 +544,7 @@ class _LoopTrainFn(torch.autograd.Function):
             st = torch.cuda.current_stream(dev).cuda_stream
             nat.train_step([p.data_ptr() for p in ps], [g.data_ptr() for g in grads], x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(),
                            y.data_ptr(), B, L, loss.data_ptr(), logits.data_ptr() if want_logits else 0, d_m.data_ptr(), d_a.data_ptr(), st)
-            if model.check_device_errors:
+            if model.check_device_errors is True:
                 nat.sync_status(st)   # waits for the stream: a busy GPU / a timed-out team kernel raises here, not as a silent NaN
         ctx.save_for_backward(d_m, d_a, *grads)
         if want_logits:
@@ -545,7 +572,7 @@ class _LoopForwardFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             nat.train_forward([p.data_ptr() for p in ps], x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(), B, L, logits.data_ptr(), st)
-            if model.check_device_errors:
+            if model.check_device_errors is True:
                 nat.sync_status(st)
         ctx.model = model
         ctx.save_for_backward(x, mels_up, aux, *ps)
@@ -565,6 +592,6 @@ class _LoopForwardFn(torch.autograd.Function):
             st = torch.cuda.current_stream(dev).cuda_stream
             nat.train_backward([p.data_ptr() for p in ps], [g.data_ptr() for g in grads], dl.data_ptr(), x.data_ptr(), mels_up.data_ptr(),
                                aux.data_ptr(), B, L, d_m.data_ptr(), d_a.data_ptr(), st)
-            if model.check_device_errors:
+            if model.check_device_errors is True:
                 nat.sync_status(st)
         return (None, None, d_m, d_a) + tuple(grads)

@@ -160,3 +160,45 @@ def test_the_fused_iteration_equals_the_reference_loop_body(tmp_path):
         curves.append(T.voc_train_loop(T.VocPaths(tmp_path / str(k)), m, lf, opt, T.WindowLoader(pairs, 2, seed=7, **kw), None, 1e-4, 3))
     assert len(curves[0]) == 4
     np.testing.assert_allclose(curves[0], curves[1], rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_deferred_status_checks_and_the_validation_pass():
+    """`check_device_errors = 'deferred'` (what voc_train_loop sets): no wait inside the training calls, `training_status()` asks once per
+    iteration -- same numbers, the host queues backward / clipping / Adam under the running step.  Under `torch.no_grad()` training_loss is
+    the forward + loss only (wrnn_train_step without gradient outputs) and gives the same value."""
+    import time
+    B, Tf = 32, 5
+    rng = np.random.Generator(np.random.PCG64(3))
+    lab = rng.integers(0, 1024, size=(B, Tf * 275 + 1))
+    x = torch.from_numpy((2.0 * lab[:, :-1] / 1023.0 - 1.0).astype(np.float32)).cuda()
+    y = torch.from_numpy(lab[:, 1:]).cuda()
+    mels = torch.from_numpy(rng.random((B, 80, Tf + 4), dtype=np.float32)).cuda()
+    curves, times = {}, {}
+    for mode in (True, 'deferred'):
+        m = _fresh('RAW')
+        m.train()
+        m.check_device_errors = mode
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        out = []
+        for it in range(7):
+            if it == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            loss = m.training_loss(x, mels, y)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([p for p in m.parameters() if p.requires_grad], 4)
+            opt.step()
+            out.append(loss.item())
+            m.training_status()
+        torch.cuda.synchronize()
+        times[mode] = (time.perf_counter() - t0) / 5
+        curves[mode] = out
+    np.testing.assert_allclose(curves['deferred'], curves[True], rtol=1e-6)
+    print(f'\n[train] B=32 x 1375, ms per iteration: checks inside every call {times[True] * 1e3:.1f}, deferred {times["deferred"] * 1e3:.1f}')
+    m.eval()                                                     # BatchNorm on running statistics for both evaluations
+    with torch.no_grad():
+        v0 = float(m.training_loss(x, mels, y))
+    v1 = float(m.training_loss(x, mels, y).detach())
+    assert abs(v0 - v1) <= 1e-6 * abs(v1), (v0, v1)
