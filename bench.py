@@ -21,7 +21,8 @@ metric = audio ksamples/s (all loop steps of all rows counted, like the referenc
 fatchord_version.py:267-271), whole job over all N GPUs; weak scaling (the per-GPU batch is fixed).
 
 The headline fields are the selected config's.  The default run (config 1, N=1) additionally times configs[2] and [4] for a
-few steps and attaches them as `extra_configs` {"2": {...}, "4": {...}} to the same JSON line (~10 s).
+few steps and attaches them as `extra_configs` {"2": {...}, "4": {...}} to the same JSON line (~10 s), plus "train_step": the
+training step of the loop layers (`wrnn_train_step`) at the reference's training shape (~1 s).
 
 Extra objects on the JSON line:
   roofline      -- ALGORITHMIC bytes (weights once per step for the whole batch + 836 B conditioning/sample, SURVEY.md
@@ -157,6 +158,54 @@ def measure_hbm_peaks(dev, nbytes: int = 1 << 30, reps: int = 8) -> dict | None:
         return {'copy': bw, 'read': bw, 'how': 'torch device copy (read + write), bench_micro/devcopy not built'}
     except Exception:   # the peak is an annotation: never sink the bench line for it
         return None
+
+
+def train_step_leg(dev, B: int = 32, frames: int = 5, iters: int = 6) -> dict:
+    """SURVEY.md 8f N4, driver-visible: `wrnn_train_step` (forward + the training script's loss + backward of the loop layers) at the
+    reference's own training shape (voc_batch_size 32 x voc_seq_len 5 hops, wavernn_hparams.py:44,51) on synthetic conditioning, timed with
+    events on the launch stream.  The upsample network and the optimiser (torch ops around it in a training iteration) are not in it."""
+    import numpy as np
+    import torch
+    from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS
+    from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+    torch.manual_seed(0)
+    m = WaveRNN(**DEFAULT_DIMS, mode='RAW')
+    m.verbose = False
+    m.to(dev).train()
+    L = frames * DEFAULT_DIMS['hop_length']
+    rng = np.random.Generator(np.random.PCG64(1))
+    x = torch.from_numpy(rng.uniform(-1, 1, (B, L)).astype(np.float32)).to(dev)
+    y = torch.from_numpy(rng.integers(0, 2 ** DEFAULT_DIMS['bits'], (B, L)).astype(np.int32)).to(dev)
+    mu = torch.from_numpy(rng.random((B, L, DEFAULT_DIMS['feat_dims']), dtype=np.float32)).to(dev)
+    au = torch.from_numpy(rng.standard_normal((B, L, DEFAULT_DIMS['res_out_dims'])).astype(np.float32)).to(dev)
+    ps = [p.detach().contiguous() for p in m._loop_params()]
+    gs = [torch.zeros_like(p) for p in ps]
+    dm, da = torch.zeros_like(mu), torch.zeros_like(au)
+    loss = torch.zeros((), device=dev)
+    nat = m._native_handle()
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+
+        def call():
+            nat.train_step([p.data_ptr() for p in ps], [g.data_ptr() for g in gs], x.data_ptr(), mu.data_ptr(), au.data_ptr(), y.data_ptr(), B, L,
+                           loss.data_ptr(), 0, dm.data_ptr(), da.data_ptr(), st)
+        for _ in range(2):
+            call()
+        nat.sync_status(st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call()
+        e1.record()
+        nat.sync_status(st)
+        ms = e0.elapsed_time(e1) / iters
+    value = float(loss)
+    del m, nat, ps, gs, dm, da, mu, au
+    torch.cuda.empty_cache()
+    return {'metric': 'training step of the loop layers (forward + loss + backward, wrnn_train_step), audio ksamples/sec', 'value': round(B * L / ms, 1),
+            'unit': 'ksamples/s', 'steps': iters, 'warmup': 2, 'ms_per_step': round(ms, 3), 'dtype': 'f32',
+            'config': {'workload': f'B={B} x L={L} teacher-forced steps (voc_batch_size x voc_seq_len of the reference), RAW 10-bit, synthetic '
+                                   'conditioning and targets, seeded random weights', 'loss': round(value, 6)}}
 
 
 def self_launch(args) -> int:
@@ -411,6 +460,10 @@ def main() -> int:
                     extra[str(cid)]['config'] = e['config']
                 except Exception as ex:  # an extra leg must never sink the headline
                     extra[str(cid)] = {'error': repr(ex)}
+            try:
+                extra['train_step'] = train_step_leg(dev)
+            except Exception as ex:
+                extra['train_step'] = {'error': repr(ex)}
             out['extra_configs'] = extra
         if world == 1 and not args.no_cpu_baseline and not dry:
             try:
