@@ -202,3 +202,16 @@ def test_deferred_status_checks_and_the_validation_pass():
         v0 = float(m.training_loss(x, mels, y))
     v1 = float(m.training_loss(x, mels, y).detach())
     assert abs(v0 - v1) <= 1e-6 * abs(v1), (v0, v1)
+
+
+def test_training_cli_fails_loudly_without_a_gpu(tmp_path, monkeypatch):
+    """`python wavernn_train.py` has no CPU path (wavernn_train.py:45 forces the CPU in the reference; here the step kernels are the product)."""
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'wavernn_train.py'), '--synthetic', '4', '--total_steps', '1'], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'MI355X' in r.stderr and not (tmp_path / 'logs_wavernn').exists()
