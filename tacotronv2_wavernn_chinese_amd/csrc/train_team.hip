@@ -15,6 +15,13 @@
 //             partials of a unit are summed by the unit's owner (reduce-scatter through the mailbox: R x 512 granules in, R x 512 out
 //             per workgroup -- the forward's volume).  v_mfma_f32_4x4x1 with block = 4 output units, i = batch row: one issue =
 //             4 rows x 64 outputs x one k.  2 barriers per step.
+//
+// Order of a step's memory traffic (measured, profiles/r03_train_step_kernel_stats.txt: 2.25 / 2.67 -> 1.70 / 1.84 us per step):
+//   * a poll opens with a SENTINEL (one 16-byte slice per lane) and reads everything once that carries the step's tag -- a full look that
+//     comes back stale is R x 4 KB of L2 reads per workgroup for nothing, and the publishes of the other workgroups queue behind them;
+//   * global loads are issued BEHIND the poll (vmcnt retires in order: a load from HBM in front of a poll holds it up), two steps ahead,
+//     into the register set the step has just consumed; the loop is unrolled by two so that the sets rotate by name;
+//   * global stores go between the publish and the first look (acknowledged by the L2, off the serial chain).
 #include "batch_common.h"
 
 // developer build (-DTT_PROF): cycles per phase of a step, summed over the launch by thread 0 of workgroup 0 of team 0, printed at the end
