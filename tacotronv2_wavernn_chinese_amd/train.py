@@ -122,6 +122,8 @@ def voc_train_loop(paths: VocPaths, model, loss_func: Optional[Callable], optimi
     for g in optimizer.param_groups:
         g['lr'] = lr
     per_epoch = len(train_set)
+    if per_epoch < 1:
+        raise ValueError('voc_train_loop: the training set is empty')
     epochs = (total_steps - model.get_step()) // per_epoch + 1
     params = [p for p in model.parameters() if p.requires_grad]
     losses = []
