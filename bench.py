@@ -242,7 +242,7 @@ def run_config(cfg_id: int, *, world: int, rank: int, dev, dry: bool, steps: int
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     if not dry:
         model.to(dev)
-    kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[kernel_name]
+    kernel = _cabi.KERNEL_IDS[kernel_name]
     T = frames
     scatter = cfg_id == 3
     if scatter and rank == 0:
@@ -393,7 +393,7 @@ def main() -> int:
     ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument('--frames', type=int, default=T_FRAMES)
     ap.add_argument('--batch', type=int, default=0, help='rows per GPU (default: the config\'s)')
-    ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'batch', 'simple'])
+    ap.add_argument('--kernel', default='auto', choices=['auto', 'team2', 'batch', 'batch_cs', 'simple'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the configs[2] / configs[4] legs of the default run')
     ap.add_argument('--phase-profile', action='store_true', help='run the instrumented loop kernel (wrnn_phase_profile) and attach cycles per phase')

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 4
+#define WRNN_ABI_VERSION 5
 
 /* mode: fatchord_version.py:98-103 */
 #define WRNN_MODE_RAW 0 /* softmax over 2**bits classes */
@@ -60,6 +60,8 @@ extern "C" {
 /* 2 was the 4-wave team kernel of ABI 2 (retired) */
 #define WRNN_KERNEL_TEAM2 3  /* one XCD-resident 32-workgroup team per row, weights on chip, critical / shadow wave roles */
 #define WRNN_KERNEL_BATCH 4  /* one team per 4 or 8 rows in lock-step on the matrix cores (v_mfma_f32_4x4x1) */
+#define WRNN_KERNEL_BATCH_CS 5 /* ABI 5: the same batch step with two waves per SIMD -- critical / shadow wave roles, the shadow
+                                * matrix products, noise and conditioning run beside the serial chain instead of inside it */
 
 /* tensor dtypes accepted by wrnn_load_weights */
 #define WRNN_DTYPE_F32 0

@@ -2,7 +2,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden [long | forward | train | dm]
 
 Every fixture stores only seeds + the reference's outputs: weights, mels and
 the sampling noise are rebuilt from the seeds on whatever box replays them
@@ -54,6 +54,8 @@ TRAIN_CASES = [
     dict(name='train_raw_peaky_b4_t5', mode='RAW', bits=10, variant='peaky', B=4, T=5),
     dict(name='train_mol_default_b4_t5', mode='MOL', bits=9, variant='default', B=4, T=5),
 ]
+# The secondary dual-softmax model (`python -m oracle.make_golden dm`): SURVEY.md 8a A12, deepmind_version.py:75-165
+DM_CASES = [dict(name='dm_h896_s2000', hidden=896, steps=2000)]
 TRAIN_GRAD_SAMPLES = 257
 WEIGHT_SEED, MEL_SEED, NOISE_SEED = 0, 1234, 42
 
@@ -129,9 +131,30 @@ def mint_forward():
         print(f"{c['name']}: logits {out['logits'].shape} loss {out['loss']:.6f} loss_sub {loss_sub:.6f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def mint_dm():
+    """deepmind_version.WaveRNN.generate(seq_len) of the unmodified reference on seeded weights: the 16-bit output and the
+    coarse / fine class indices of every step.  Stored with the seeds only; tests/test_deepmind.py replays the Exp(1) draws
+    (oracle.noise.dm_noise_from_seed) and checks them against the checksum kept here."""
+    from oracle import ref_harness as rh
+    from oracle.noise import dm_noise_from_seed
+    from tacotronv2_wavernn_chinese_amd.synth import make_dm_state_dict
+    for c in DM_CASES:
+        sd = make_dm_state_dict(WEIGHT_SEED, hidden_size=c['hidden'])
+        out = rh.reference_dm_generate(sd, c['steps'], NOISE_SEED)
+        q = dm_noise_from_seed(NOISE_SEED, c['steps'])
+        path = os.path.join(GOLDEN_DIR, c['name'] + '.npz')
+        np.savez_compressed(path, weight_seed=WEIGHT_SEED, noise_seed=NOISE_SEED, steps=c['steps'],
+                            coarse=out['coarse'].astype(np.int16), fine=out['fine'].astype(np.int16), output=out['output'].astype(np.int32),
+                            noise_checksum=noise_checksum({'q': q}))
+        print(f"{c['name']}: {c['steps']} steps -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main() -> int:
     from oracle import ref_harness as rh
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dm':
+        mint_dm()
+        return 0
     if len(sys.argv) > 1 and sys.argv[1] == 'forward':
         mint_forward()
         return 0

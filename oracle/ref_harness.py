@@ -21,8 +21,9 @@ Non-semantic shims needed to import the reference under this image
 
 Randomness: the reference draws through the global torch CPU generator.
 ``torch.multinomial(p, 1, True)`` on CPU is ``argmax(p / q)`` with
-``q = empty_like(p).exponential_(1)`` (verified bit-identical in
-``tests/test_oracle_reference.py``), so the noise the reference consumed for a
+``q = empty_like(p).exponential_(1)`` (verified: every label of every golden fixture
+is the reference's own ``multinomial`` draw, and ``tests/test_oracle_golden.py``
+reproduces all of them from the replayed ``q``), so the noise the reference consumed for a
 given ``torch.manual_seed`` is *replayed* here by re-seeding and issuing the
 same ``exponential_`` / ``uniform_`` calls -- no monkeypatching of the
 sampler.  ``torch.multinomial`` / the MOL sampler are wrapped only to *record*

@@ -18,12 +18,13 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libwavernn_amd.so')
 
 MODE_RAW, MODE_MOL = 0, 1
 NOISE_PHILOX, NOISE_INJECTED, NOISE_ARGMAX = 0, 1, 2
-KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM2, KERNEL_BATCH = 0, 1, 3, 4
-KERNEL_NAMES = {KERNEL_AUTO: 'auto', KERNEL_SIMPLE: 'simple', KERNEL_TEAM2: 'team2', KERNEL_BATCH: 'batch'}
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TEAM2, KERNEL_BATCH, KERNEL_BATCH_CS = 0, 1, 3, 4, 5
+KERNEL_NAMES = {KERNEL_AUTO: 'auto', KERNEL_SIMPLE: 'simple', KERNEL_TEAM2: 'team2', KERNEL_BATCH: 'batch', KERNEL_BATCH_CS: 'batch_cs'}
+KERNEL_IDS = {v: k for k, v in KERNEL_NAMES.items()}
 DTYPE_F32, DTYPE_I64 = 0, 1
 ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN_ERR_STATE',
              -4: 'WRNN_ERR_MISSING_KEY', -5: 'WRNN_ERR_TIMEOUT', -6: 'WRNN_ERR_BUSY'}
-ABI_VERSION = 4   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding was written against
+ABI_VERSION = 5   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding was written against
 
 # every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',

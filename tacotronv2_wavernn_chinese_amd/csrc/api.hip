@@ -162,6 +162,10 @@ int wrnn_create(const wrnn_config *cfg, wrnn_handle **out) {
             hipError_t e = wrnn_batch_occupancy(cfg->mode, nq, false, &blocks, &lds);
             if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_batch_kernel cannot be resident (LDS/registers)"; }
         }
+        for (int nq = 1; nq <= wrnn_batch_cs_max_nq(cfg->mode) && h->team_ok; ++nq) {
+            hipError_t e = wrnn_batch_cs_occupancy(cfg->mode, nq, false, &blocks, &lds);
+            if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_batch_cs_kernel cannot be resident (LDS/registers)"; }
+        }
         (void)hipGetLastError();
     }
     for (int i = 0; i < 3; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
@@ -546,14 +550,15 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     }
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));
-    } else if (kernel == WRNN_KERNEL_TEAM2 || kernel == WRNN_KERNEL_BATCH) {
+    } else if (kernel == WRNN_KERNEL_TEAM2 || kernel == WRNN_KERNEL_BATCH || kernel == WRNN_KERNEL_BATCH_CS) {
+        const bool batch_family = kernel != WRNN_KERNEL_TEAM2;
         if (team_no) return fail(h, WRNN_ERR_INVALID, "%s", team_no);
         // conditioning pushed through the linear layers it feeds (once per call)
         const int H = d.H, FC = d.FC, F = d.F, A = d.A, R = d.R, P = d.P;
         const int TP = T + 2 * P, T1 = T + 1;
         const size_t nCM = (size_t)B * TP * H, nCA = (size_t)B * T1 * H, nVM = (size_t)B * TP * 3 * H, nVA = (size_t)B * T1 * 3 * H;
         const size_t nC2 = (size_t)B * T1 * 3 * H, nC3 = (size_t)B * T1 * FC, nC4 = (size_t)B * T1 * FC;
-        const size_t nREC = (size_t)B * T1 * H * (kernel == WRNN_KERNEL_BATCH ? 32 : 28);
+        const size_t nREC = (size_t)B * T1 * H * (batch_family ? 32 : 28);
         const size_t need = nCM + nCA + nVM + nVA + nC2 + nC3 + nC4 + nREC;
         if (need > h->tab_cap) {
             if (h->tab) (void)hipFree(h->tab);
@@ -572,13 +577,15 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 2 * A, (size_t)T * R, R, T, w + o.fc1_t + (size_t)H * FC, FC, w + o.fc1_b, tC3, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         HIP_TRY(h, wrnn_launch_frame_linear(0, h->aux_frames + 3 * A, (size_t)T * R, R, T, w + o.fc2_t + (size_t)FC * FC, FC, w + o.fc2_b, tC4, (size_t)T1 * FC, T1, A, FC, B, T, P, s));
         const size_t mail_bytes = (size_t)8 * WRNN_MAIL_GRANULES_MAX * sizeof(unsigned long long);
-        if (kernel == WRNN_KERNEL_BATCH) {
+        if (batch_family) {
             // R = 4 * nq rows per XCD team in lock-step on the matrix cores (loop_batch.hip); the rows are spread evenly over
             // the teams first (rpb rows per batch), a team runs ceil(batches / n_teams) batches one after the other
             HIP_TRY(h, wrnn_launch_pack_records32(tCM, tCA, tVM, tVA, tC2, tC3, tC4, tREC, B, T, P, s));
             int rpb = (rows + h->n_teams - 1) / h->n_teams;
             if (rpb > WRNN_BATCH_MAX_ROWS) rpb = WRNN_BATCH_MAX_ROWS;
             if (opts->batch_rows > 0) rpb = opts->batch_rows;
+            const bool cs = kernel == WRNN_KERNEL_BATCH_CS;   // critical / shadow wave roles (loop_batch_cs.hip)
+            if (cs && rpb > 4 * wrnn_batch_cs_max_nq(d.mode)) rpb = 4 * wrnn_batch_cs_max_nq(d.mode);
             WrnnBatchArgs ba{};
             ba.w = w; ba.off = o; ba.d = d; ba.batch_w = h->batch_w; ba.batch_fc3 = h->batch_fc3; ba.batch_wn = h->batch_wn; ba.wI0 = h->wI0; ba.u1 = h->u1;
             ba.tabREC32 = tREC; ba.rows = h->rows_dev; ba.order = h->order_dev; ba.snake = snake; ba.n_rows = rows; ba.n_teams = h->n_teams; ba.nq = rpb <= 4 ? 1 : 2; ba.rpb = rpb;
@@ -593,7 +600,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             HIP_TRY(h, wrnn_team_gate_enter(h->cfg.device, s));
             hipError_t le = hipMemsetAsync(h->mail, 0, mail_bytes, s);
             if (le == hipSuccess) le = hipMemsetAsync(h->ctl, 0, 128, s);
-            if (le == hipSuccess) le = wrnn_launch_loop_batch(ba, s);
+            if (le == hipSuccess) le = cs ? wrnn_launch_loop_batch_cs(ba, s) : wrnn_launch_loop_batch(ba, s);
             const hipError_t ge = wrnn_team_gate_leave(h->cfg.device, s);
             HIP_TRY(h, le);
             HIP_TRY(h, ge);
@@ -706,6 +713,7 @@ int wrnn_phase_profile(wrnn_handle *h, int32_t enable) {
         if (h->team_ok) {
             hipError_t e = wrnn_team2_occupancy(h->cfg.mode, true, &blocks, &lds);
             for (int nq = 1; nq <= 2 && e == hipSuccess && blocks >= 1; ++nq) e = wrnn_batch_occupancy(h->cfg.mode, nq, true, &blocks, &lds);
+            for (int nq = 1; nq <= wrnn_batch_cs_max_nq(h->cfg.mode) && e == hipSuccess && blocks >= 1; ++nq) e = wrnn_batch_cs_occupancy(h->cfg.mode, nq, true, &blocks, &lds);
             (void)hipGetLastError();
             if (e != hipSuccess || blocks < 1) return fail(h, WRNN_ERR_INVALID, "the instrumented team kernels cannot be resident on this device");
         }

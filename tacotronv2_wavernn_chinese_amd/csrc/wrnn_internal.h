@@ -267,6 +267,10 @@ hipError_t wrnn_launch_loop_simple(const WrnnLoopArgs &a, hipStream_t s);
 size_t wrnn_simple_lds_bytes(const WrnnDims &d);
 hipError_t wrnn_launch_loop_batch(const WrnnBatchArgs &a, hipStream_t s);
 hipError_t wrnn_batch_occupancy(int mode, int nq, bool prof, int *blocks_per_cu, size_t *lds_bytes);
+// loop_batch_cs.hip: the same step with critical / shadow wave roles (two waves per SIMD); nq as built (wrnn_batch_cs_max_nq)
+hipError_t wrnn_launch_loop_batch_cs(const WrnnBatchArgs &a, hipStream_t s);
+hipError_t wrnn_batch_cs_occupancy(int mode, int nq, bool prof, int *blocks_per_cu, size_t *lds_bytes);
+int wrnn_batch_cs_max_nq(int mode);
 hipError_t wrnn_team2_occupancy(int mode, bool prof, int *blocks_per_cu, size_t *lds_bytes);
 // Per-device ordering of team-kernel launches inside this process (api.hip): enter() makes `s` wait for the previous team
 // kernel launched on `device` by any handle / stream and takes the device's launch lock, leave() records the new tail and

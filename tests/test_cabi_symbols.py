@@ -16,7 +16,8 @@ def test_library_exports_every_declared_symbol():
     lib = _cabi.load_library()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.wrnn_abi_version() == 4 == _cabi.ABI_VERSION
+    hdr_abi = int(re.search(r"#define WRNN_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.wrnn_abi_version() == hdr_abi == _cabi.ABI_VERSION
 
 
 def test_create_rejects_bad_config_without_gpu():
@@ -69,12 +70,13 @@ def test_stale_library_is_refused(monkeypatch):
     """load_library() compares wrnn_abi_version() with the ABI the binding was written against: a stale .so (a git-ignored
     build artefact) must fail at load, not read the structs at shifted offsets."""
     from tacotronv2_wavernn_chinese_amd import _cabi
+    real = _cabi.ABI_VERSION
     monkeypatch.setattr(_cabi, '_lib', None)
-    monkeypatch.setattr(_cabi, 'ABI_VERSION', 3)
+    monkeypatch.setattr(_cabi, 'ABI_VERSION', real - 1)
     with pytest.raises(RuntimeError, match='ABI'):
         _cabi.load_library()
-    monkeypatch.setattr(_cabi, 'ABI_VERSION', 4)
-    assert _cabi.load_library().wrnn_abi_version() == 4
+    monkeypatch.setattr(_cabi, 'ABI_VERSION', real)
+    assert _cabi.load_library().wrnn_abi_version() == real
 
 
 def test_generate_refuses_an_unknown_opts_struct_size():

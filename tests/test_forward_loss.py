@@ -43,13 +43,13 @@ def _model(fx, kernel):
     m.verbose = False
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in fx['state_dict'].items()})
     m.to('cuda:0')
-    m.kernel = {'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[kernel]
+    m.kernel = _cabi.KERNEL_IDS[kernel]
     m.eval()   # the goldens are the reference's eval-mode forward; in train() mode forward() is the differentiable pass (test_train_step.py)
     return m
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kernel', ['team2', 'batch', 'simple'])
+@pytest.mark.parametrize('kernel', ['team2', 'batch', 'batch_cs', 'simple'])
 @pytest.mark.parametrize('name', CASES)
 def test_forward_matches_the_reference(name, kernel):
     """forward(x, mels) on the loop kernels (fed-back value forced to x, first step fed x[:, 0], pre-padded mels) vs the

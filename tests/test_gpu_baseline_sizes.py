@@ -37,7 +37,7 @@ def _model(sd, mode='RAW', bits=10, kernel='auto'):
     m.verbose = False
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     m.to('cuda:0')
-    m.kernel = {'auto': _cabi.KERNEL_AUTO, 'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE}[kernel]
+    m.kernel = _cabi.KERNEL_IDS[kernel]
     return m
 
 
@@ -209,7 +209,7 @@ def test_config4_mol_b32_t401_full_size_rows():
     _mol_case(32, 401, [0, 13, 22, 31], 'configs[4] MOL B=32 T=401, batch kernel')
 
 
-@pytest.mark.parametrize('kernel', ['team2', 'batch'])
+@pytest.mark.parametrize('kernel', ['team2', 'batch', 'batch_cs'])
 def test_b8_t60_reference_golden(kernel):
     """A reference-minted golden long enough for several natural segments per row at B = 8 (16 500 steps, no developer
     knob): the latency kernel (one row per XCD team, 8 default segments) and the batch kernel (forced: 8 teams x 1 row
@@ -229,7 +229,7 @@ def test_b8_t60_reference_golden(kernel):
         np.testing.assert_array_equal(got, fx['labels'].astype(np.int32))
 
 
-@pytest.mark.parametrize('kernel', ['team2', 'batch', 'simple'])
+@pytest.mark.parametrize('kernel', ['team2', 'batch', 'batch_cs', 'simple'])
 def test_raw_9bit_has_no_phantom_classes(kernel):
     """RAW with bits < 10 (n_classes < 1024): workgroups / quarter-waves that own no class must not enter the race.
     Labels stay below n_classes and match the oracle."""

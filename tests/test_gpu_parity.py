@@ -12,7 +12,7 @@ from tests.parity_util import check_free_run_raw, check_mol, check_teacher_force
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ['team2', 'batch', 'simple']
+KERNELS = ['team2', 'batch', 'batch_cs', 'simple']
 # The straightforward one-workgroup kernel runs ~1 ms/step: it is exercised on the B=3 case (3 rows in
 # parallel) and on the fold case only; the team kernel (the shipped path) runs every case.
 SIMPLE_CASES = {'raw_peaky_b3_t21', 'raw_peaky_fold_t30', 'mol_default_b2_t21'}
@@ -33,7 +33,7 @@ def _model(fx, kernel='auto'):
     m.verbose = False
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in fx['state_dict'].items()})
     m.to('cuda:0')
-    m.kernel = {'simple': _cabi.KERNEL_SIMPLE, 'batch': _cabi.KERNEL_BATCH, 'team2': _cabi.KERNEL_TEAM2, 'auto': _cabi.KERNEL_AUTO}[kernel]
+    m.kernel = _cabi.KERNEL_IDS[kernel]
     return m
 
 
@@ -285,7 +285,7 @@ def test_philox_sampling_is_distributionally_correct():
     assert len(np.unique(got)) > 50
 
 
-@pytest.mark.parametrize('kernel', ['team2', 'batch'])
+@pytest.mark.parametrize('kernel', ['team2', 'batch', 'batch_cs'])
 def test_many_rows_are_scheduled_independently(kernel):
     """BASELINE configs[2]-style batch: 19 rows (two full waves of 8 XCD teams + a ragged tail).  Greedy sampling
     (q == 1), rows 0..18 use 3 distinct mels in rotation: rows with the same mel must produce identical label
@@ -361,7 +361,7 @@ def test_edge_shapes_and_bad_arguments():
     from tacotronv2_wavernn_chinese_amd.synth import make_mels
     fx = load_case('raw_peaky_b1_t24')
     om = orc.OracleModel(fx['state_dict'], fast=True)
-    for kernel in ('team2', 'batch'):
+    for kernel in ('team2', 'batch', 'batch_cs'):
         m = _model(fx, kernel)
         for T in (1, 2, 5):                      # shorter than the 5-frame upsampling support / the fade-out
             mels = make_mels(100 + T, 1, T)

@@ -22,7 +22,7 @@ def _model(kernel):
     m.verbose = False
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     m.to('cuda:0')
-    m.kernel = {'team2': _cabi.KERNEL_TEAM2, 'batch': _cabi.KERNEL_BATCH, 'simple': _cabi.KERNEL_SIMPLE, 'auto': _cabi.KERNEL_AUTO}[kernel]
+    m.kernel = _cabi.KERNEL_IDS[kernel]
     return m, sd
 
 
@@ -35,7 +35,7 @@ def _padded(lens, seed):
     return batch
 
 
-@pytest.mark.parametrize('kernel,n', [('batch', 19), ('batch', 70), ('team2', 11), ('simple', 3)])
+@pytest.mark.parametrize('kernel,n', [('batch', 19), ('batch', 70), ('batch_cs', 19), ('batch_cs', 70), ('team2', 11), ('simple', 3)])
 def test_ragged_rows_equal_the_padded_call_and_stop_at_their_own_length(kernel, n):
     """Greedy sampling (no noise arrays): a ragged call against the padded call on the same kernel -- the valid part of every
     row bit-equal, nothing written past a row's own length -- and row 0..2 against the oracle."""
@@ -139,7 +139,7 @@ def test_two_handles_share_a_gpu_without_timeouts():
     np.testing.assert_array_equal(out['b'], solo2)
 
 
-@pytest.mark.parametrize('mode,kernel,B', [('RAW', 'team2', 3), ('RAW', 'batch', 12), ('RAW', 'batch', 40), ('MOL', 'batch', 12)])
+@pytest.mark.parametrize('mode,kernel,B', [('RAW', 'team2', 3), ('RAW', 'batch', 12), ('RAW', 'batch', 40), ('MOL', 'batch', 12), ('RAW', 'batch_cs', 12), ('MOL', 'batch_cs', 12)])
 def test_phase_profile_runs_the_instrumented_kernels_with_the_same_results(mode, kernel, B):
     """wrnn_phase_profile / wrnn_phase_cycles (ABI 4; ABI 3 read an environment variable): the instrumented instantiations of the
     team kernels ship in the library, so they are tested like everything else -- same labels / samples as the plain kernel,
@@ -155,7 +155,7 @@ def test_phase_profile_runs_the_instrumented_kernels_with_the_same_results(mode,
     m.verbose = False
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     m.to('cuda:0')
-    m.kernel = _cabi.KERNEL_TEAM2 if kernel == 'team2' else _cabi.KERNEL_BATCH
+    m.kernel = _cabi.KERNEL_IDS[kernel]
     mels = make_mels(3, B, 6)
     nat = m.native()
     plain = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=9)

@@ -178,8 +178,10 @@ def test_fold_target_gives_at_most_one_fold_per_team():
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` with no WORLD_SIZE around it must become the launcher (the driver's SCALE command):
-    on this GPU-less box both ranks get as far as the device check and say so."""
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it must become the launcher (the driver's SCALE command): on this
+    GPU-less box the ranks get as far as the device check and say so.  torchrun tears the sibling down as soon as the first rank
+    exits 3, so only ONE such message is guaranteed (asking for both made this test fail 2 runs in 3 inside the full suite);
+    that two ranks really start, meet and time together is tests/test_sharding.py's dry run of the same self-launch."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -191,7 +193,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
     else:
         assert r.returncode != 0
-        assert r.stderr.count('no HIP device visible') >= 2 or 'invalid device ordinal' in r.stderr, r.stderr[-2000:]
+        assert r.stderr.count('no HIP device visible') >= 1 or 'invalid device ordinal' in r.stderr, r.stderr[-2000:]
+        assert 'torch.distributed' in r.stderr or 'ChildFailedError' in r.stderr or 'exitcode' in r.stderr, r.stderr[-2000:]   # it WAS the launcher
 
 
 def test_philox_replays_agree():

@@ -130,3 +130,24 @@ def test_bench_distributed_scaffolding_dry_run(tmp_path):
         if cfg == '3':
             assert d['dry_run_check'] == 'ok'
             assert d['value'] == pytest.approx(2 * 2 * 3 * 21 * 275 / (d['ms_per_step'] * 2 / 1e3) / 1e3, rel=1e-3)
+
+
+def test_bench_scaffolding_at_the_real_rank_count(tmp_path):
+    """The driver's SCALE run uses 8 ranks; this is the same self-launch at world 8 on CPU (gloo, dry run): rank -> device
+    mapping, the scatter of 8 x 2 clips from rank 0, the gather of every rank's waveforms, the barrier and the MAX reduction
+    of the elapsed time at the rank count the 8-GPU node will use."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--cpu-dry-run', '--config', '3', '--steps', '2',
+                        '--warmup', '1', '--frames', '21', '--batch', '2'], capture_output=True, text=True, timeout=900, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['dry_run_check'] == 'ok' and d['scaling'] == 'weak'
+    assert d['value'] == pytest.approx(8 * 2 * 2 * 21 * 275 / (d['ms_per_step'] * 2 / 1e3) / 1e3, rel=1e-3)

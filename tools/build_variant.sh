@@ -1,11 +1,23 @@
 #!/bin/bash
-# Build an experimental variant of the library next to the product one:  tools/build_variant.sh NAME -DMACRO=1 ...
-# -> build_variants/libNAME.so (git-ignored; travels to the GPU box with gpurun).  Used with tools/ab_bench.py.
+# Build an experimental variant of the library next to the product one:
+#   tools/build_variant.sh NAME file1,file2 -DMACRO=1 ...      (files = the .hip sources, without extension, the macros apply to)
+# -> build_variants/libNAME.so (git-ignored; travels to the GPU box with gpurun): the named sources recompiled with the extra flags,
+# every other object taken from the product build (csrc/.obj).  Used with tools/ab_bench.py / tools/ab_configs.sh.
 set -e
-name=${1:?usage: build_variant.sh NAME [hipcc flags]}; shift
+name=${1:?usage: build_variant.sh NAME file1,file2 [hipcc flags]}; files=${2:?files}; shift 2
 cd "$(dirname "$0")/../tacotronv2_wavernn_chinese_amd/csrc"
-mkdir -p ../../build_variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -no-hip-rt -Wno-unused-result "$@" \
-  api.hip prologue.hip loop_simple.hip loop_team2.hip loop_batch.hip loop_deepmind.hip loop_dm_team.hip epilogue.hip losses.hip train.hip train_team.hip \
-  -o ../../build_variants/lib$name.so 2>&1 | grep -E "error" || true
+make -s -j8
+mkdir -p ../../build_variants .obj_var/$name
+objs=""
+for o in .obj/*.o; do
+  b=$(basename $o .o)
+  if [[ ",$files," == *",$b,"* ]]; then
+    extra=""; [ "$b" = loop_batch_cs ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed $extra "$@" -c $b.hip -o .obj_var/$name/$b.o
+    objs="$objs .obj_var/$name/$b.o"
+  else
+    objs="$objs $o"
+  fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -no-hip-rt $objs -o ../../build_variants/lib$name.so
 ls -la ../../build_variants/lib$name.so
