@@ -21,8 +21,10 @@ metric = audio ksamples/s (all loop steps of all rows counted, like the referenc
 fatchord_version.py:267-271), whole job over all N GPUs; weak scaling (the per-GPU batch is fixed).
 
 The headline fields are the selected config's.  The default run (config 1, N=1) additionally times configs[2] and [4] for a
-few steps and attaches them as `extra_configs` {"2": {...}, "4": {...}} to the same JSON line (~10 s), plus "train_step": the
-training step of the loop layers (`wrnn_train_step`) at the reference's training shape (~1 s).
+few steps and attaches them as `extra_configs` {"2": {...}, "4": {...}} to the same JSON line (~10 s), plus "fold_auto": ONE 5 s utterance
+in the reference's fold mode with target='auto' (one fold per XCD: single-utterance latency) and "train_step": the
+training step of the loop layers (`wrnn_train_step`) at the reference's training shape (~1 s each).  A run on N > 1
+GPUs (config 1) attaches `extra_configs` {"3": {...}}: BASELINE configs[3] (64 clips per GPU, scatter / gather over RCCL) at that N.
 
 Extra objects on the JSON line:
   roofline      -- ALGORITHMIC bytes (weights once per step for the whole batch + 836 B conditioning/sample, SURVEY.md
@@ -36,8 +38,9 @@ Extra objects on the JSON line:
                    register/LDS resident and HBM is idle: the bound that actually binds is the exchange latency,
                    `latency_model` = {exchanges per step, all-gather round time of the 32 workgroups of one XCD measured by
                    bench_micro/handoff, floor_us} and `frac_of_latency_floor` = floor / measured us per step.
-  cpu_baseline  -- the CPU restatement (oracle/, "port") timed on this box's host cores on BASELINE configs[0]'s clip
-                   (80x200, 55 000 steps), rank 0 at N=1 only;
+  cpu_baseline  -- the reference's generate() loop issued op for op on PyTorch-CPU on THIS box's host cores (oracle/torch_cpu_loop.py,
+                   kind "reference-ops (torch CPU, this box)": all cores + one thread, a bounded sample of BASELINE configs[0]'s clip),
+                   rank 0 at N=1 only;  cpu_port -- the C restatement (oracle/wavernn_oracle.c, OpenMP + AVX2) on the same clip;
   cpu_reference -- the UNMODIFIED reference generate() (PyTorch CPU) timed by oracle/time_reference.py where
                    /root/reference exists (the build container; `where` says so) -- the GPU box has no reference tree.
 """
@@ -81,6 +84,32 @@ TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_463_506 + 1_913_781,            # fetch_c
 LATENCY_MODEL = dict(exchanges_per_step=4, barriers_per_step=5, allgather_round_us=0.746, raw_hop_us=0.27,
                      source='profiles/r03_handoff_microbench.txt (gather st=plain ld=sc1 team=32: 0.746-0.768 us per round; '
                             'raw one-way hop profiles/r01_handoff_microbench.txt)')
+
+
+def cpu_reference_ops(frames: int = 200, steps: int = 3000) -> dict:
+    """The reference's generate() loop issued op for op on PyTorch-CPU ON THIS BOX (oracle/torch_cpu_loop.py: nn.GRUCell /
+    nn.Linear / softmax / Categorical.sample() as fatchord_version.py:194-237; pinned to the reference's own labels by
+    tests/test_oracle_golden.py), on BASELINE configs[0]'s clip, a bounded sample of its 55 000 steps, all cores and one thread."""
+    from oracle import torch_cpu_loop as tl
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
+    sd = make_state_dict(0, variant='peaky')
+    mels = make_mels(1234, 1, frames)
+    ncpu = os.cpu_count() or 1
+    # torch's default is one thread per core; on a many-core host that is the WORST setting for 512-wide matrix-vector products (every op
+    # is an OpenMP barrier), so the leg also runs at <= 16 threads and reports the best of the two as `value` -- with both kept
+    threads = sorted({ncpu, min(ncpu, 16)}, reverse=True)
+    tl.run(sd, mels, 32, threads[-1], max_seconds=5.0)   # first-call overheads (thread pool, MKL plans)
+    runs = [tl.run(sd, mels, steps, th, max_seconds=8.0) for th in threads]
+    one = tl.run(sd, mels, max(200, steps // 3), 1, max_seconds=6.0)
+    rate = lambda r: r['steps'] / max(r['loop_seconds'], 1e-9) / 1000.0
+    allc = max(runs, key=rate)
+    by_threads = {str(r['threads']): round(rate(r), 4) for r in runs}
+    return dict(value=round(rate(allc), 4), unit='ksamples/s', cores=allc['threads'], host_cores=ncpu, by_threads=by_threads,
+                kind='reference-ops (torch CPU, this box)',
+                one_thread=round(one['steps'] / one['loop_seconds'] / 1000.0, 4),
+                sample=f'BASELINE configs[0] clip (mel 80x{frames}, RAW 10-bit, B=1): the first {allc["steps"]} of its {frames * HOP} loop steps with the '
+                       f'reference\'s own op sequence on torch-CPU ({allc["loop_seconds"]:.1f} s on {allc["threads"]} threads of {ncpu} cores; {one["steps"]} steps in '
+                       f'{one["loop_seconds"]:.1f} s on 1 thread); oracle/torch_cpu_loop.py, reproduces the reference\'s labels bit for bit')
 
 
 def cpu_baseline(frames: int = 200, max_threads: int = 16) -> dict:
@@ -206,6 +235,48 @@ def train_step_leg(dev, B: int = 32, frames: int = 5, iters: int = 6) -> dict:
             'unit': 'ksamples/s', 'steps': iters, 'warmup': 2, 'ms_per_step': round(ms, 3), 'dtype': 'f32',
             'config': {'workload': f'B={B} x L={L} teacher-forced steps (voc_batch_size x voc_seq_len of the reference), RAW 10-bit, synthetic '
                                    'conditioning and targets, seeded random weights', 'loss': round(value, 6)}}
+
+
+def fold_auto_leg(dev, frames: int = T_FRAMES, reps: int = 3) -> dict:
+    """The reference's own fast mode ("batched ... very fast (realtime+)", wavernn_hparams.py:55-57, fatchord_version.py:293-405) as a
+    single-utterance LATENCY figure: one 5 s clip, generate(batched=True, target='auto') = one fold per XCD team, crossfaded and
+    unfolded on the device; value = wave_len / wall time of the whole generate() call (prologue, loop, epilogue, wav file)."""
+    import tempfile
+    import torch
+    from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_mels, make_state_dict
+    from tacotronv2_wavernn_chinese_amd.vocoder import WaveRNN
+    sd = make_state_dict(0, variant='peaky')
+    m = WaveRNN(**DEFAULT_DIMS, mode='RAW')
+    m.verbose = False
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m.to(dev)
+    mels = make_mels(1000, 1, frames)
+    wave_len = (frames - 1) * HOP
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'o.wav')
+        m.generate(mels, path, True, 'auto', 550, True, epilogue='device', seed=1)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            wav = m.generate(mels, path, True, 'auto', 550, True, epilogue='device', seed=2 + i)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+    tm = m.last_timing
+    assert wav.shape == (wave_len,)
+    out = {'metric': 'single-utterance latency mode: audio ksamples/sec of ONE clip in fold mode, target=auto (one fold per XCD team)',
+           'value': round(wave_len / dt / 1000.0, 1), 'unit': 'ksamples/s', 'steps': reps, 'warmup': 1, 'ms_per_step': round(dt * 1e3, 3), 'dtype': 'f32',
+           'config': {'workload': f'one utterance, mel 80x{frames} ({wave_len / SAMPLE_RATE:.3f} s of audio), generate(batched=True, target="auto", overlap=550), '
+                                  f'{tm["rows"]} folds x {tm["steps"]} loop steps, RAW 10-bit, device epilogue (crossfade + unfold), wav written',
+                      'times_real_time': round(wave_len / SAMPLE_RATE / dt, 1), 'loop_kernel_ms': round(tm['loop_ms'], 3),
+                      'prologue_ms': round(tm['prologue_ms'], 3), 'kernel': _kernel_name(tm['kernel'])}}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
+def _kernel_name(k: int) -> str:
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    return _cabi.KERNEL_NAMES.get(k, str(k))
 
 
 def self_launch(args) -> int:
@@ -374,7 +445,7 @@ def run_config(cfg_id: int, *, world: int, rank: int, dev, dry: bool, steps: int
         'roofline': roof,
     }
     if phases is not None:
-        out['phase_cycles_per_step'] = {f'wave{w}': [round(float(c)) for c in phases[w] if c > 0] for w in range(8) if phases[w].any()}
+        out['phase_cycles_per_step'] = {f'wave{w}': {str(i): round(float(c)) for i, c in enumerate(phases[w]) if c > 0} for w in range(8) if phases[w].any()}
     if dry:
         out['data'] = 'dry-run (CPU stand-in for the device calls: not a measurement)'
         if scatter and world > 1:   # every rank's waveforms came back, and they are the ones of the clips it was sent
@@ -448,11 +519,25 @@ def main() -> int:
                      batch=args.batch, kernel_name=args.kernel, copy_peak=copy_peak, dump=args.dump, phase_profile=args.phase_profile)
     default_run = (args.config == 1 and world == 1 and not dry and not args.no_extra_configs and args.frames == T_FRAMES
                    and args.batch == 0 and args.kernel == 'auto')
+    # the driver's SCALE command (`--gpus N`, config 1 by default) also reports BASELINE configs[3] at that N: 64 clips per GPU scattered
+    # from / gathered on rank 0 over RCCL -- one line carries the weak B=1-per-GPU number and the throughput-mode number
+    scale_extra = None
+    if args.config == 1 and world > 1 and not args.no_extra_configs and args.batch == 0 and args.kernel == 'auto':
+        try:
+            scale_extra = run_config(3, world=world, rank=rank, dev=dev, dry=dry, steps=2, warmup=1, frames=args.frames, batch=(2 if dry else 0),
+                                     kernel_name='auto', copy_peak=None)
+        except Exception as ex:   # every rank raises or none does (the collectives are symmetric); never sink the headline
+            scale_extra = {'error': repr(ex)}
     if rank == 0 and out is not None:
+        if scale_extra is not None:
+            keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'roofline', 'config', 'data', 'dry_run_check', 'error')
+            out['extra_configs'] = {'3': {k: scale_extra[k] for k in keep if k in scale_extra}}
         if default_run:
             # configs[2] and [4] in the driver's own run: a few steps each, attached to the headline line
             extra = {}
+            note = lambda m: print(f'bench.py: [{time.strftime("%H:%M:%S")}] {m}', file=sys.stderr, flush=True)
             for cid in (2, 4):
+                note(f'extra leg configs[{cid}]')
                 try:
                     e = run_config(cid, world=1, rank=0, dev=dev, dry=False, steps=2, warmup=1, frames=T_FRAMES, batch=0, kernel_name='auto',
                                    copy_peak=copy_peak)
@@ -460,17 +545,31 @@ def main() -> int:
                     extra[str(cid)]['config'] = e['config']
                 except Exception as ex:  # an extra leg must never sink the headline
                     extra[str(cid)] = {'error': repr(ex)}
+            note('extra leg fold_auto')
+            try:
+                extra['fold_auto'] = fold_auto_leg(dev)
+            except Exception as ex:
+                extra['fold_auto'] = {'error': repr(ex)}
+            note('extra leg train_step')
             try:
                 extra['train_step'] = train_step_leg(dev)
             except Exception as ex:
                 extra['train_step'] = {'error': repr(ex)}
             out['extra_configs'] = extra
         if world == 1 and not args.no_cpu_baseline and not dry:
+            # cpu_baseline = the reference's own op sequence on torch-CPU on THIS box (the closest obtainable thing to "the reference CPU
+            # wavernn_gen.py on the host cores of the same box": /root/reference does not exist here); cpu_port = the C restatement
+            print('bench.py: cpu_baseline leg (torch CPU reference ops)', file=sys.stderr, flush=True)
             try:
-                out['cpu_baseline'] = cpu_baseline()
+                out['cpu_baseline'] = cpu_reference_ops()
             except Exception as e:  # the baseline must never sink the bench line
-                out['cpu_baseline'] = {'value': None, 'unit': 'ksamples/s', 'cores': 0, 'kind': 'port',
+                out['cpu_baseline'] = {'value': None, 'unit': 'ksamples/s', 'cores': 0, 'kind': 'reference-ops (torch CPU, this box)',
                                        'sample': f'failed: {e!r}'}
+            print('bench.py: cpu_port leg (C restatement)', file=sys.stderr, flush=True)
+            try:
+                out['cpu_port'] = cpu_baseline()
+            except Exception as e:
+                out['cpu_port'] = {'value': None, 'unit': 'ksamples/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {e!r}'}
             ref = cpu_reference()
             if ref:
                 out['cpu_reference'] = ref

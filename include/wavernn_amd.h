@@ -54,7 +54,7 @@ extern "C" {
 #define WRNN_NOISE_ARGMAX 2   /* RAW only: greedy (q == 1) */
 
 /* which device implementation runs the per-sample loop */
-#define WRNN_KERNEL_AUTO 0   /* rows <= XCD teams: TEAM2 (latency); more rows: BATCH (throughput); SIMPLE when the team
+#define WRNN_KERNEL_AUTO 0   /* rows <= XCD teams: TEAM2 (latency); more rows: BATCH_CS (throughput); SIMPLE when the team
                               * kernels cannot run on this device / configuration */
 #define WRNN_KERNEL_SIMPLE 1 /* one workgroup per row, weights streamed from L2/HBM; any shape */
 /* 2 was the 4-wave team kernel of ABI 2 (retired) */

@@ -546,7 +546,9 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     else if (d.ND != 5 || d.HOP > 275) team_no = "team kernels are built for pad=2 (5-frame upsampling support), hop <= 275";
     if (kernel == WRNN_KERNEL_AUTO) {
         if (team_no) kernel = WRNN_KERNEL_SIMPLE;
-        else kernel = rows <= h->n_teams ? WRNN_KERNEL_TEAM2 : WRNN_KERNEL_BATCH;   // one row per XCD team: the latency kernel
+        // one row per XCD team: the latency kernel; more rows: the batch step with critical / shadow wave roles (round 4: 7.5 against 6.85
+        // Msamples/s at RAW B = 64, 5.6 against 5.3 at MOL B = 32; WRNN_KERNEL_BATCH stays available by name)
+        else kernel = rows <= h->n_teams ? WRNN_KERNEL_TEAM2 : WRNN_KERNEL_BATCH_CS;
     }
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));

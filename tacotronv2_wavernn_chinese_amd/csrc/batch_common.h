@@ -194,7 +194,7 @@ struct NoMid { __device__ __forceinline__ void operator()() const {} };
 
 // acc[g][q] += W_g (32 slabs at w[g*32 ..]) . x for NG weight rows sharing the B operand; xv = LDS vector as f4 [rq][S][lane];
 // mid() runs before slab MS (the early request of the next exchange's granules)
-template <int NQ, int NG, bool AG, int D, class F, int MS = 4>
+template <int NQ, int NG, bool AG, int D, class F, int MS = 4, bool EVERY = false>
 __device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc)[NG][NQ], F mid) {
     f4 ring[D][NQ];
 #pragma unroll
@@ -203,7 +203,7 @@ __device__ __forceinline__ void mfma_gates(const float *w, lds_cf4p xv, f4 (&acc
         for (int q = 0; q < NQ; ++q) ring[dd][q] = xv[(q * 8 + dd) * 64];
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
-        if (S == MS) mid();
+        if (EVERY || S == MS) mid();   // EVERY: a hook in front of every slab (loop_batch_cs.hip: the shadow wave yields to the critical one)
         f4 b[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) b[q] = ring[S % D][q];

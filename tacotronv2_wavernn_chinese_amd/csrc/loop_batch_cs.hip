@@ -27,8 +27,7 @@
 
 #define CS_THREADS 512
 // developer knobs (tools/build_variant.sh): CS_PRIO 1 = the C waves run at s_setprio 3; CS_GATHER 0 = sentinel first, 1 = a full look at once,
-// 2 = s_sleep(CS_DELAY) and then a full look (both with the sentinel fall-back); CS_YIELD 1 = an S wave starts a matrix phase only once the C
-// wave of its SIMD has published and is polling (token in LDS)
+// 2 = s_sleep(CS_DELAY) and then a full look (both with the sentinel fall-back); CS_YIELD 1 = an S wave issues no MFMA while the C wave of its SIMD folds / evaluates gates (token in LDS)
 #ifndef CS_PRIO
 #define CS_PRIO 1
 #endif
@@ -40,6 +39,12 @@
 #endif
 #ifndef CS_YIELD
 #define CS_YIELD 0
+#endif
+#ifndef CS_LATE_H1
+#define CS_LATE_H1 1   // 1 = the S waves gather h1' BEHIND barrier B1 (one look, the data is long there) and synchronise among themselves through LDS flags
+#endif
+#ifndef CS_MAX_NQ
+#define CS_MAX_NQ 2   // row quads per team this file is built for
 #endif
 
 namespace {
@@ -58,9 +63,10 @@ struct LayCS {
     static constexpr int L_Q = L_P + VEC;           // x3
     static constexpr int L_H1 = L_Q + VEC;          // h1', later fc1 outputs
     static constexpr int L_XN = L_H1 + VEC;
+    static constexpr int L_LG = L_H1;               // [R][32] MOL: the 30 fc3 outputs of every batch row, in window 5 (H1 is dead from B4 to the next h1' gather)
     static constexpr int L_MISC = L_XN + 16;
-    static constexpr int L_PROF = L_MISC + 16;      // [8 waves][24]
-    static constexpr int L_TOTAL = L_PROF + 192;
+    static constexpr int L_PROF = L_MISC + 16;      // [2 roles][24]: phase cycles of wave 0 (C) and wave 4 (S), instrumented build only
+    static constexpr int L_TOTAL = L_PROF + 48;
     static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
     static_assert((L_P % 4) == 0, "B operands are read as 16-byte vectors");
 };
@@ -96,7 +102,7 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
             __builtin_amdgcn_sched_barrier(0);                                 \
             const unsigned now_ = (unsigned)__builtin_readcyclecounter();      \
             __builtin_amdgcn_sched_barrier(0);                                 \
-            if (lane == 0) prof_lds[wave * 24 + (i)] += now_ - prof_last;      \
+            if (lane == 0 && wl == 0) prof_lds[(wave >> 2) * 24 + (i)] += now_ - prof_last; \
             prof_last = now_;                                                  \
         }                                                                      \
     } while (0)
@@ -111,6 +117,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     float *lds = (float *)smem;
     int *misc_i = (int *)(lds + L::L_MISC);
     float *xn = lds + L::L_XN;
+    float *lgt = lds + L::L_LG;
+    float *molnz = lds + L::L_HAND + H_NZ * SL;   // MOL: [parity][R][16] noise of the rows' samplers (the RAW nz slots are unused there)
+    static_assert(2 * R * 16 <= 4 * SL, "MOL noise fits the nz slots");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,8 +172,12 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)mail, 0, (int)(WRNN_BATCH_MAIL_GRANULES * 8u), 0x00020000);
 
     const int unit = 16 * g + 4 * wl + iu;
-    const int cls0 = 32 * g + 8 * wl + iu;
-    const bool wg_has_fc3 = 32 * g < NC;
+    // RAW: workgroup g owns classes 32 g .. 32 g + 31 (fc3 is output-split like every other layer, the race needs an exchange).
+    // MOL: fc3 has 30 rows -- every workgroup holds ALL of them (the 64 KB LDS image the RAW slice would occupy) and evaluates them
+    // redundantly from the gathered fc2 outputs: no fifth exchange (round 3 had workgroup 0 evaluate them while 31 others waited for
+    // its 30 granules: one more L2 round trip on the serial chain).
+    const int cls0 = (MODE == WRNN_MODE_MOL ? 0 : 32 * g) + 8 * wl + iu;
+    const bool wg_has_fc3 = MODE == WRNN_MODE_MOL || 32 * g < NC;
     const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
     const unsigned gvoff = (unsigned)tl * 16u;
     // compact slot index of this thread's (unit, row): duplicates (kp2 >= NQ) read their primary lane's entry (an LDS broadcast)
@@ -184,7 +197,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
             for (int i = 0; i < 160; ++i) wv[i] = src[(size_t)(96 + i) * 64];
         }
-        const float4 *f3 = (const float4 *)(a.batch_fc3 + (size_t)g * 16384);
+        const float4 *f3 = (const float4 *)(a.batch_fc3 + (size_t)(MODE == WRNN_MODE_MOL ? 0 : g) * 16384);
         float4 *dst = (float4 *)(lds + L::L_FC3);
         for (int i = tid; i < 4096; i += CS_THREADS) dst[i] = f3[i];
         const float4 *wn = (const float4 *)(a.batch_wn + (size_t)g * 8192);
@@ -211,7 +224,10 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const lds_fp hand = (lds_fp)(size_t)launder(smem_base + (unsigned)L::L_HAND * 4u + (unsigned)ci * 4u);
     const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + 2u * (unsigned)(tl & 31)) * 4u);
 
-    volatile int *tok = (volatile int *)(misc_i + 4 + wl);   // CS_YIELD: C wave wl -> S wave wl "published, polling now" (epoch * 8 + window)
+    volatile int *tok = (volatile int *)(misc_i + 4 + wl);   // CS_YIELD: C wave wl -> S wave wl of the same SIMD: 1 = "in a dependent VALU chain, keep the matrix pipe free"
+    volatile int *sflag = (volatile int *)(misc_i + 8);         // CS_LATE_H1: S-wave meeting point (epoch of the H1 each wave has written)
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    volatile i4v *sflag4 = (volatile i4v *)(misc_i + 8);
     bool dead = false;
     unsigned epoch = 0;
     unsigned *prof_lds = (unsigned *)(lds + L::L_PROF);
@@ -283,6 +299,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                     mfma_gates<NQ, 3, false, DG>(wv, vP, acc, NoMid());
+                    if (CS_YIELD && lane == 0) *tok = 1;   // the fold and the gates are a dependent VALU chain: the shadow wave's MFMAs wait
                     PBW(4);
                     float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -297,7 +314,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     h2 = (1.0f - zg) * ng + zg * h2;
                     const float x3 = x2own + h2;
                     if (primary) st_granule(mail, LM::G_X3 + par * LM::RG + mb_own, epoch, __float_as_uint(x3));
-                    if (CS_YIELD && lane == 0) *tok = (int)(epoch * 8u + 2u);
+                    if (CS_YIELD && lane == 0) *tok = 0;
                 }
                 PBW(6);
                 {
@@ -321,7 +338,6 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         if (q == 0 || my_rq == q) s = f;
                     }
                     if (primary) st_granule(mail, LM::G_F1 + par * LM::RG + mb_own, epoch, __float_as_uint(fmaxf(s + hand[H_C3 * SL], 0.0f)));
-                    if (CS_YIELD && lane == 0) *tok = (int)(epoch * 8u + 3u);
                 }
                 PBW(11);
                 {
@@ -406,7 +422,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                             if (q == 0 || my_rq == q) { lg0 = f0; lg1 = f1; }
                         }
                         lg0 += cst[C_B30 * SL]; lg1 += cst[C_B31 * SL];
-                        if (a.logits_out && primary && row_ok && t < rw.steps) {
+                        if (a.logits_out && primary && row_ok && t < rw.steps && (MODE != WRNN_MODE_MOL || g == 0)) {
                             float *lo = a.logits_out + ((size_t)t * a.n_rows + row) * NC;
                             if (cls0 < NC) lo[cls0] = lg0;
                             if (cls0 + 4 < NC) lo[cls0 + 4] = lg1;
@@ -439,13 +455,12 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                             st_granule(mail, LM::G_PR + par * LM::PRG + (unsigned)rb * 128u + (unsigned)(g * 4 + wl),
                                        (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
                     } else {
-                        if (wg_has_fc3 && primary) {
-                            if (cls0 < NC) st_granule(mail, LM::G_PR + par * LM::PRG + (unsigned)rb * 128u + (unsigned)cls0, epoch, __float_as_uint(lg0));
-                            if (cls0 + 4 < NC) st_granule(mail, LM::G_PR + par * LM::PRG + (unsigned)rb * 128u + (unsigned)(cls0 + 4), epoch, __float_as_uint(lg1));
-                        }
+                        // MOL: the wave's 8 fc3 outputs of every batch row -> LDS; wave w samples batch rows w, w + 4 behind the barrier
+                        if (primary) { lgt[rb * 32 + cls0] = lg0; lgt[rb * 32 + cls0 + 4] = lg1; }
                     }
                 }
                 PBW(20);
+                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b
                 u4v gqa[NQ];
                 if (MODE == WRNN_MODE_RAW) {
                     const unsigned tg = epoch & 0x3fffffu;
@@ -462,11 +477,19 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     }
                 }
                 PBW(21);
+                // The teacher-forced value (forward(): x_forced) is fetched HERE, behind the poll's own wait, and the output stores of
+                // workgroup 0 go out after the LAST row's value is in LDS: with the load and the stores inside the per-row code the
+                // compiler had to put an `s_waitcnt vmcnt(0)` in front of the second row -- workgroup 0, the one every other workgroup
+                // waits for at the next exchange, sat there until the first row's global stores were acknowledged (~500 cycles per row).
+                float xfv[NQ], xnv[NQ];
+                int labv[NQ];
+#pragma unroll
+                for (int bi = 0; bi < NQ; ++bi) xfv[bi] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + frow[bi]] : 0.0f;
+#pragma unroll
+                for (int bi = 0; bi < NQ; ++bi) asm volatile("" : "+v"(xfv[bi]));   // waited for here, once
 #pragma unroll
                 for (int bi = 0; bi < NQ; ++bi) {
                     const int brow = wl + 4 * bi;
-                    const int rrow = frow[bi];
-                    const bool rok = t < fsteps[bi];
                     float x_new;
                     int lab;
                     if (MODE == WRNN_MODE_RAW) {
@@ -483,27 +506,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     } else {
                         // sample_from_discretized_mix_logistic (distribution.py:87-123) for batch row `brow`
                         const int nr = NC / 3;
-                        float nzv = 0.0f;
-                        if (lane <= nr) {
-                            float u;
-                            if (a.noise_mode == WRNN_NOISE_INJECTED)
-                                u = lane < nr ? a.noise1[((size_t)t * a.n_rows + rrow) * nr + lane] : a.noise2[(size_t)t * a.n_rows + rrow];
-                            else
-                                u = 1e-5f + wrnn_uniform(a.seed, (uint64_t)t, (uint32_t)rrow, (uint32_t)lane) * (1.0f - 2e-5f);
-                            nzv = lane < nr ? -logf(-logf(u)) : logf(u) - logf(1.0f - u);
-                        }
-                        float mylg = 0.0f;
-                        {
-                            const u64 *gp = mail + LM::G_PR + par * LM::PRG + (unsigned)brow * 128u + (unsigned)(lane < NC ? lane : 0);
-                            u64 gq = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            unsigned spins = 0;
-                            while (!dead && !__all((unsigned)(gq >> 32) == epoch)) {
-                                if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 27u); break; }
-                                __builtin_amdgcn_s_sleep(1);
-                                gq = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            mylg = __uint_as_float((unsigned)gq);
-                        }
+                        // the Gumbel / logistic noise of (step, row) was prepared by the S wave of this SIMD (noise_step)
+                        const float nzv = lane <= nr ? molnz[((int)par * R + brow) * 16 + lane] : 0.0f;
+                        const float mylg = lgt[brow * 32 + (lane < NC ? lane : 0)];
                         const float v = lane < nr ? mylg + nzv : -INFINITY;
                         const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(v)), 63));
                         const u64 ball = __ballot(v == mx);
@@ -514,11 +519,15 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         x_new = fminf(fmaxf(mean + expf(ls) * nlog, -1.0f), 1.0f);
                         lab = km;
                     }
-                    if (lane == 0) {
-                        xn[brow] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + rrow] : x_new;   // (:237)
-                        if (g == 0 && rok) {
-                            if (a.labels_out) a.labels_out[(size_t)rrow * a.steps + t] = lab;
-                            a.samples_out[(size_t)rrow * a.steps + t] = x_new;
+                    xnv[bi] = x_new; labv[bi] = lab;
+                    if (lane == 0) xn[brow] = a.x_forced ? xfv[bi] : x_new;   // (:237)
+                }
+                if (lane == 0 && g == 0) {
+#pragma unroll
+                    for (int bi = 0; bi < NQ; ++bi) {
+                        if (t < fsteps[bi]) {   // a real row that has not reached its own length (ragged batch)
+                            if (a.labels_out) a.labels_out[(size_t)frow[bi] * a.steps + t] = labv[bi];
+                            a.samples_out[(size_t)frow[bi] * a.steps + t] = xnv[bi];
                         }
                     }
                 }
@@ -563,8 +572,30 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 }
             };
             // -log q of this thread's two classes for step ts (RAW) -> nz slots of parity `np` (see loop_batch.hip for the Philox block)
+            int frowS[NQ];   // rows whose sampler the C wave of this SIMD runs (MOL: their noise is prepared here)
+#pragma unroll
+            for (int bi = 0; bi < NQ; ++bi) {
+                const int brow = wl + 4 * bi, s0 = batch * a.rpb + brow;
+                frowS[bi] = a.order[(brow < a.rpb && s0 < a.n_rows) ? s0 : a.n_rows - 1];
+            }
             auto noise_step = [&](int64_t ts, unsigned np) {
-                if (MODE != WRNN_MODE_RAW) return;
+                if (MODE != WRNN_MODE_RAW) {
+                    // sample_from_discretized_mix_logistic (distribution.py:106-121): 10 Gumbel draws (mixture pick) + 1 logistic draw per row
+                    const int nr = NC / 3;
+#pragma unroll
+                    for (int bi = 0; bi < NQ; ++bi) {
+                        const int brow = wl + 4 * bi, rrow = frowS[bi];
+                        if (lane <= nr) {
+                            float u;
+                            if (a.noise_mode == WRNN_NOISE_INJECTED)
+                                u = lane < nr ? a.noise1[((size_t)ts * a.n_rows + rrow) * nr + lane] : a.noise2[(size_t)ts * a.n_rows + rrow];
+                            else
+                                u = 1e-5f + wrnn_uniform(a.seed, (uint64_t)ts, (uint32_t)rrow, (uint32_t)lane) * (1.0f - 2e-5f);
+                            molnz[((int)np * R + brow) * 16 + lane] = lane < nr ? -logf(-logf(u)) : logf(u) - logf(1.0f - u);
+                        }
+                    }
+                    return;
+                }
                 float nz0, nz1;
                 if (a.noise_mode == WRNN_NOISE_INJECTED) {
                     const float *qp = a.noise1 + ((size_t)ts * a.n_rows + row) * NC;
@@ -601,7 +632,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 if (PROF) prof_last = (unsigned)__builtin_readcyclecounter();
 
                 // ---------------- window 1: gather h1' -> H1 ----------------
-                {
+                if (!CS_LATE_H1) {
                     u4v gx[1][NM];
                     gather_sf<NM>(mrs, gvoff, (LM::G_H1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 22u);
                     PBW(1);
@@ -611,17 +642,35 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(2);
                 __syncthreads();   // B1
                 PBW(3);
+                if (CS_LATE_H1) {
+                    // h1' is not needed before this wave's own W_hh1 product: fetched HERE, the S waves are never the last to reach B1 (they
+                    // were: their 32 KB look ran beside the C waves' x2 look through the same 64 B/clk port) and the x2 look has the port
+                    // to itself.  The four S waves then meet through LDS flags (s_barrier would need the C waves).
+                    u4v gx[1][NM];
+                    const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
+                    gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
+                    PBW(1);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    if (lane == 0) sflag[wl] = (int)epoch;
+                    for (unsigned sp = 0; sp < 200000u; ++sp) {
+                        const i4v f = *sflag4;
+                        if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
+                    }
+                }
 
                 // ---------------- window 2: gh1 of the next step = W_hh1 . h1' + b_hh1 ----------------
-                if (CS_YIELD) { for (unsigned sp = 0; sp < 100000u && *tok < (int)(epoch * 8u + 2u); ++sp) __builtin_amdgcn_s_sleep(1); }
-                PBW(4);
                 {
                     f4 acc[3][NQ];
 #pragma unroll
                     for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                    mfma_gates<NQ, 3, false, DG>(wv, vH1, acc, NoMid());
+                    // Between two slabs the S wave looks at the token of the C wave it shares the SIMD with: while C folds phase B and
+                    // evaluates the GRU2 gates (a dependent VALU chain; measured 2 270 cycles with this wave's MFMAs in the matrix pipe,
+                    // 1 050 without) it issues nothing.  During C's own MFMAs both keep issuing: two waves fill the pipe (4 cycles per MFMA).
+                    auto yield = [&]() { if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); } };
+                    mfma_gates<NQ, 3, false, DG, decltype(yield), 0, CS_YIELD != 0>(wv, vH1, acc, yield);
                     PBW(7);
                     float gr = 0.f, gz = 0.f, gn = 0.f;
 #pragma unroll
@@ -636,8 +685,6 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(10);
 
                 // ---------------- window 3: gh2 of the next step = W_hh2 . (x3 - x2) + b_hh2 (gate n's weights from LDS) ----------------
-                if (CS_YIELD) { for (unsigned sp = 0; sp < 100000u && *tok < (int)(epoch * 8u + 3u); ++sp) __builtin_amdgcn_s_sleep(1); }
-                PBW(11);
                 {
                     f4 acc[3][NQ];
 #pragma unroll
@@ -690,6 +737,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(19);
 
                 // ---------------- window 5: conditioning of the next step ----------------
+                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: C's fc3 outputs of all rows are in LDS
                 if (t + 1 < bsteps) cond_step(t + 1);
                 PBW(17);
                 __syncthreads();   // B5
@@ -703,8 +751,8 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
         }
         __syncthreads();
     }
-    if (PROF && a.prof && lane == 0 && g == 0 && team == 0) {
-        for (int i = 0; i < 24; ++i) a.prof[wave * WRNN_PROF_SLOTS + i] += prof_lds[wave * 24 + i];
+    if (PROF && a.prof && lane == 0 && wl == 0 && g == 0 && team == 0) {   // reported as "wave 0" (C) and "wave 4" (S)
+        for (int i = 0; i < 24; ++i) a.prof[wave * WRNN_PROF_SLOTS + i] += prof_lds[(wave >> 2) * 24 + i];
     }
 }
 
@@ -725,11 +773,14 @@ static hipError_t launch_cs(const WrnnBatchArgs &a, hipStream_t s) {
 }
 
 // row quads per team this file is built for (a.nq = 1: 4 rows per team)
-int wrnn_batch_cs_max_nq(int mode) { (void)mode; return 1; }
+int wrnn_batch_cs_max_nq(int mode) { (void)mode; return CS_MAX_NQ; }
 
 hipError_t wrnn_launch_loop_batch_cs(const WrnnBatchArgs &a, hipStream_t s) {
     (void)hipGetLastError();
-    if (a.nq != 1) return hipErrorInvalidValue;
+    if (a.nq < 1 || a.nq > CS_MAX_NQ) return hipErrorInvalidValue;
+#if CS_MAX_NQ >= 2
+    if (a.nq == 2) return a.d.mode == WRNN_MODE_RAW ? launch_cs<WRNN_MODE_RAW, 2>(a, s) : launch_cs<WRNN_MODE_MOL, 2>(a, s);
+#endif
     if (a.d.mode == WRNN_MODE_RAW) return launch_cs<WRNN_MODE_RAW, 1>(a, s);
     return launch_cs<WRNN_MODE_MOL, 1>(a, s);
 }
@@ -744,7 +795,10 @@ static hipError_t occ_cs(bool prof, int *blocks_per_cu, size_t *lds_bytes) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, CS_THREADS, lds);
 }
 hipError_t wrnn_batch_cs_occupancy(int mode, int nq, bool prof, int *blocks_per_cu, size_t *lds_bytes) {
-    if (nq != 1) return hipErrorInvalidValue;
+    if (nq < 1 || nq > CS_MAX_NQ) return hipErrorInvalidValue;
+#if CS_MAX_NQ >= 2
+    if (nq == 2) return mode == WRNN_MODE_RAW ? occ_cs<WRNN_MODE_RAW, 2>(prof, blocks_per_cu, lds_bytes) : occ_cs<WRNN_MODE_MOL, 2>(prof, blocks_per_cu, lds_bytes);
+#endif
     if (mode == WRNN_MODE_RAW) return occ_cs<WRNN_MODE_RAW, 1>(prof, blocks_per_cu, lds_bytes);
     return occ_cs<WRNN_MODE_MOL, 1>(prof, blocks_per_cu, lds_bytes);
 }

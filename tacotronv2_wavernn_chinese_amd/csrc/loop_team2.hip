@@ -73,17 +73,63 @@ __device__ __forceinline__ void finish_n(const u64 *base, unsigned idx, unsigned
 // One exchange, one granule per thread, two staggered first looks: look A is issued right away (it catches the
 // case where every producer was early), look B `T2_STAGGER` sleeps later; A is examined when it returns, B only
 // if A came back incomplete, the bounded re-read loop only if B is incomplete too.
+#ifndef T2_DEFER_OUT
+#define T2_DEFER_OUT 0   // developer knob: 1 = a shadow wave stores a step's outputs one step later (measured round 4: 297 -> 293.5 ksamples/s, not kept)
+#endif
 #ifndef T2_STAGGER
 #define T2_STAGGER 3
 #endif
-__device__ __forceinline__ unsigned take_granule(const u64 *base, unsigned idx, unsigned tag, bool &dead, unsigned *err, unsigned code) {
-    u64 ga[1], gb[1];
+// Round 4: the caller owns look B's registers (`gb`) and RETIRES them behind the barrier that follows the exchange (retire_look).
+// Written as `return all_ok(A) ? A : finish(B)` the compiler merged the two results with a v_cndmask behind `s_waitcnt vmcnt(0)`:
+// every exchange waited for look B -- issued T2_STAGGER sleeps (~190 cycles) after look A -- even when A already carried the data,
+// 4 times per step on the serial chain.  The empty asm pins the A path's result to look A alone.
+#ifndef T2_PRESLEEP
+#define T2_PRESLEEP 0   // developer knob: s_sleep units in front of the first look
+#endif
+#ifndef T2_LATE_B
+#define T2_LATE_B 2   // 2 = ONE look, then the re-read loop (shipped); 1 = two staggered looks, B retired late; 0 = the round-3 code (two looks, B always waited for)
+#endif
+__device__ __forceinline__ unsigned take_granule(const u64 *base, unsigned idx, unsigned tag, bool &dead, unsigned *err, unsigned code, u64 (&gb)[1]) {
+    u64 ga[1];
+#if T2_PRESLEEP
+    __builtin_amdgcn_s_sleep(T2_PRESLEEP);
+#endif
     peek_n<1>(base, idx, 1, ga);
+#if T2_LATE_B == 2   // one look, then the re-read loop
+    finish_n<1, 32>(base, idx, 1, tag, ga, dead, err, code);
+    return (unsigned)ga[0];
+#else
     __builtin_amdgcn_s_sleep(T2_STAGGER);
     peek_n<1>(base, idx, 1, gb);
-    if (__all(tags_ok<1, 32>(ga, tag))) return (unsigned)ga[0];
+    if (__all(tags_ok<1, 32>(ga, tag))) {
+        unsigned r = (unsigned)ga[0];
+#if T2_LATE_B
+        asm volatile("" : "+v"(r));
+#endif
+        return r;
+    }
+#if T2_LATE_B
+    // `gb` keeps its single definition (the load above): re-reads go into their own registers -- a variable that is loaded on one
+    // path and re-loaded on another becomes a phi, and the copy into the phi's register is a wait for the load on EVERY path
+    if (__all(tags_ok<1, 32>(gb, tag))) { unsigned r = (unsigned)gb[0]; asm volatile("" : "+v"(r)); return r; }
+    u64 gc[1];
+    peek_n<1>(base, idx, 1, gc);
+    finish_n<1, 32>(base, idx, 1, tag, gc, dead, err, code);
+    unsigned r = (unsigned)gc[0];
+    asm volatile("" : "+v"(r));   // every path hands over a value that is waited for on that path
+    return r;
+#else
     finish_n<1, 32>(base, idx, 1, tag, gb, dead, err, code);
     return (unsigned)gb[0];
+#endif
+#endif
+}
+// look B has returned by the time the gathered value is in LDS and the workgroup barrier is passed: waiting for it HERE costs nothing and
+// leaves no load pending whose registers the compiler would have to guard with a vmcnt(0) somewhere on the serial chain
+__device__ __forceinline__ void retire_look(u64 (&gb)[1]) {
+#if T2_LATE_B
+    asm volatile("" ::"v"(gb[0]));
+#endif
 }
 
 template <int CTRL>
@@ -447,6 +493,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
         }
         __syncthreads();
 
+        int out_k = 0;
+        float out_x = 0.0f;
+        u64 lookb[1] = {0};   // the second look of an exchange (take_granule), retired behind the exchange's barrier
         for (int64_t t = a.seg0; t < seg_end; ++t) {
             ++epoch;
             const unsigned par = epoch & 1u;
@@ -487,6 +536,10 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 const float x3u = x2u + ((1.0f - zg) * ng + zg * h2o);
                 if (q == 0) st_granule(mail, G_X3 + par * 512 + unit, epoch, __float_as_uint(x3u));
             } else {
+                if (T2_DEFER_OUT && MODE == WRNN_MODE_RAW && g == 0 && tid == 256 && t > a.seg0) {   // outputs of step t - 1 (see the merge at the end of the step)
+                    if (a.labels_out) a.labels_out[(size_t)row * a.steps + t - 1] = out_k;
+                    a.samples_out[(size_t)row * a.steps + t - 1] = out_x;
+                }
                 // ---- S: gh1 for the next step = W_hh1 . h1' + b_hh1, published for everyone ----
                 float sr, sz, sn;
                 __builtin_amdgcn_s_sleep(2);   // let the critical waves' x2 reads go first
@@ -501,12 +554,13 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(2);
             // ---- exchange 1 (all threads, granule tid): x3 = x + h2 ; h2' = x3 - x2 ----
             {
-                const float x3 = __uint_as_float(take_granule(mail, G_X3 + par * 512 + tid, epoch, dead, a.err, 11u));
+                const float x3 = __uint_as_float(take_granule(mail, G_X3 + par * 512 + tid, epoch, dead, a.err, 11u, lookb));
                 xb[XB_X3 * XB_VEC + pj] = x3;
                 xb[XB_H2 * XB_VEC + pj] = x3 - x2_j;
             }
             P2(3);
             __syncthreads();  // B2
+            retire_look(lookb);
             P2(4);
 
             if (isC) {
@@ -520,10 +574,11 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(5);
             // ---- exchange 2: fc1 outputs ----
             {
-                xb[XB_F1 * XB_VEC + pj] = __uint_as_float(take_granule(mail, G_F1 + par * 512 + tid, epoch, dead, a.err, 12u));
+                xb[XB_F1 * XB_VEC + pj] = __uint_as_float(take_granule(mail, G_F1 + par * 512 + tid, epoch, dead, a.err, 12u, lookb));
             }
             P2(6);
             __syncthreads();  // B3
+            retire_look(lookb);
             P2(7);
 
             if (isC) {
@@ -537,10 +592,11 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             P2(8);
             // ---- exchange 3: fc2 outputs ----
             {
-                xb[XB_F2 * XB_VEC + pj] = __uint_as_float(take_granule(mail, G_F2 + par * 512 + tid, epoch, dead, a.err, 13u));
+                xb[XB_F2 * XB_VEC + pj] = __uint_as_float(take_granule(mail, G_F2 + par * 512 + tid, epoch, dead, a.err, 13u, lookb));
             }
             P2(9);
             __syncthreads();  // B4
+            retire_look(lookb);
             P2(10);
 
             if (isC) {
@@ -627,7 +683,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                         float xs = mean + expf(ls) * misc_f[32 + 16 * par + nr];
                         xs = fminf(fmaxf(xs, -1.0f), 1.0f);
                         if (lane == 0) {
-                            misc_f[M_XF] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + row] : xs;
+                            float xf = xs;
+                            if (a.x_forced) { float v = a.x_forced[(size_t)t * a.n_rows + row]; asm volatile("" : "+v"(v)); xf = v; }
+                            misc_f[M_XF] = xf;
                             if (g == 0) {
                                 if (a.labels_out) a.labels_out[(size_t)row * a.steps + t] = km;
                                 a.samples_out[(size_t)row * a.steps + t] = xs;
@@ -669,11 +727,24 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 if (m1.z > bv) { bv = m1.z; bk = __float_as_int(m1.w); }
                 // sample = 2 * k / (n_classes - 1.) - 1.   (:235)
                 const float x_new = 2.0f * (float)bk / ((float)NC - 1.0f) - 1.0f;
-                xfeed = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + row] : x_new;   // (:237)
+                // (:237) The teacher-forced value is waited for INSIDE its branch: with `cond ? load : x_new` the compiler cannot know at
+                // the top of the next step whether a load into xfeed is pending and opens EVERY step with `s_waitcnt vmcnt(0)` -- which also
+                // waits for workgroup 0's output stores just below and for the S waves' conditioning prefetch of step t + 2 (round 4,
+                // found in the ISA; the same in loop_batch*.hip).
+                xfeed = x_new;
+                if (a.x_forced) { float v = a.x_forced[(size_t)t * a.n_rows + row]; asm volatile("" : "+v"(v)); xfeed = v; }
+                // The outputs of step t are stored one step LATER by a shadow wave of workgroup 0 (window 2 below; after the loop for the
+                // last step).  Stored here by thread 0, a critical wave, they cost the serial chain a store acknowledgement per step: the
+                // step loop opens with `s_waitcnt vmcnt(0)` (take_granule's second look may still be in flight when the first one is
+                // taken, so the compiler must assume pending loads wherever their registers are reused), and that wait also covered these
+                // two stores, issued a few instructions before it -- in the one workgroup whose x3 every other workgroup then waits for.
+                out_k = bk; out_x = x_new;
+#if !T2_DEFER_OUT
                 if (g == 0 && tid == 0) {
                     if (a.labels_out) a.labels_out[(size_t)row * a.steps + t] = bk;
                     a.samples_out[(size_t)row * a.steps + t] = x_new;
                 }
+#endif
             } else {
                 xfeed = misc_f[M_XF];
             }
@@ -684,6 +755,10 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
             }
         }
         __syncthreads();
+        if (T2_DEFER_OUT && MODE == WRNN_MODE_RAW && g == 0 && tid == 256 && seg_end > a.seg0) {   // the last step's outputs
+            if (a.labels_out) a.labels_out[(size_t)row * a.steps + seg_end - 1] = out_k;
+            a.samples_out[(size_t)row * a.steps + seg_end - 1] = out_x;
+        }
         if (seg_end < (RAGGED ? (int64_t)a.rows[row].steps : a.steps)) {   // hand the recurrent state to the next segment's launch
             if (g == 0) {
                 st[tid] = h1_j;

@@ -623,7 +623,9 @@ hipError_t run_steps(WrnnTrainState *st, hipGraphExec_t *slot, bool rebuild, hip
         hipGraph_t g = nullptr;
         if ((e = hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal)) != hipSuccess) return e;
         launch_all(st->cap);
-        if ((e = hipStreamEndCapture(st->cap, &g)) != hipSuccess) return e;
+        const hipError_t le = hipGetLastError();   // a launch refused inside the capture (e.g. an over-limit LDS size) is reported as itself
+        if ((e = hipStreamEndCapture(st->cap, &g)) != hipSuccess) return le != hipSuccess ? le : e;
+        if (le != hipSuccess) { if (g) (void)hipGraphDestroy(g); return le; }
         e = hipGraphInstantiate(slot, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) return e;
@@ -694,6 +696,15 @@ static int train_impl(wrnn_handle *h, int phase, const wrnn_loop_params *w, cons
                          st->b_hh[1] != bhh[1];
     st->B = B; st->L = L;
     for (int i = 0; i < 2; ++i) { st->w_hh[i] = whh[i]; st->b_hh[i] = bhh[i]; }
+    if (rebuild) {
+        // ALL four graphs go at once: a forward-only call (wrnn_train_forward, or phase 1 of the split pass) re-captures only the
+        // forward graphs, and a backward graph kept from the previous (B, L, workspace, weights) would replay with those baked in
+        // -- stale grid, stale (possibly freed) pointers -- as soon as wrnn_train_backward follows (round-3 advisor finding)
+        for (int i = 0; i < 2; ++i) {
+            if (st->g_fwd[i]) { (void)hipGraphExecDestroy(st->g_fwd[i]); st->g_fwd[i] = nullptr; }
+            if (st->g_bwd[i]) { (void)hipGraphExecDestroy(st->g_bwd[i]); st->g_bwd[i] = nullptr; }
+        }
+    }
     (void)hipGetLastError();
     if (do_fwd) T_TRY(hipMemsetAsync(h->err_dev, 0, 64, s));   // device error word of the team kernels (wrnn_sync_status)
     auto *fwd_k = H == 512 ? gru_fwd_step_kernel<512> : gru_fwd_step_kernel<0>;

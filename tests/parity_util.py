@@ -17,9 +17,41 @@ north star asks for.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 NEAR_TIE = 1e-4       # RAW: relative gap of the two best p/q scores
+# How often a near-tie may happen: at most 1 + one per 100 000 compared steps (observed so far: 0 on configs[1], 1 in 882 200 on
+# configs[2]).  A near-tie picks the oracle's RUNNER-UP class, which need not be adjacent: |dlabel| at those steps is recorded
+# (bound_near_ties, parity_report) so that the distance from the north star's literal "+-1 LSB" is a tracked number.
+NEAR_TIE_RATE = 1e-5
+# The BASELINE-size tests check a subset of the rows of configs[2] / [4] over all 110 275 steps; the subset rotates with this
+# number (bumped every round) so that over the rounds every (team, position) pair is covered.
+ROW_ROTATION = 4
+_REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_report.txt')
+
+
+def parity_report(line: str) -> None:
+    """One line per parity check into gpurun_out/parity_report.txt (merged back from the GPU box; copied to profiles/ per round)."""
+    print('\n[parity] ' + line)
+    try:
+        os.makedirs(os.path.dirname(_REPORT), exist_ok=True)
+        with open(_REPORT, 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+def bound_near_ties(tag: str, compared: int, near_ties) -> None:
+    """Assert the near-tie RATE and record count + max |dlabel| of the near-tie steps.  near_ties: [(t, row, |dlabel|)]."""
+    allowed = 1 + int(compared * NEAR_TIE_RATE)
+    worst = max((d for _, _, d in near_ties), default=0)
+    parity_report(f'{tag}: steps compared {compared}, near-tie divergences {len(near_ties)} (allowed {allowed}), max |dlabel| at a near-tie '
+                  f'{worst}, identical everywhere else; near-tie steps (t, row, |dlabel|): {list(near_ties)[:8]}')
+    assert len(near_ties) <= allowed, f'{tag}: {len(near_ties)} near-ties in {compared} steps (allowed {allowed})'
+
+
 NEAR_TIE_MOL = 1e-4   # MOL: absolute gap of the two best Gumbel scores
 MOL_LSB = 2.0 / (2 ** 9 - 1)
 

@@ -33,7 +33,7 @@ def test_config3_scatter_generate_epilogue_gather_on_one_rank(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 1 and d['config']['kernel'] == 'batch' and 'RCCL' in d['config']['workload']
+    assert d['n_gpus'] == 1 and d['config']['kernel'] in ('batch', 'batch_cs') and 'RCCL' in d['config']['workload']
     z = np.load(dump)
     wave, lab, smp = z['wave'], z['labels'], z['samples']
     L, wave_len = T * 275, (T - 1) * 275

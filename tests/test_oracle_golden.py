@@ -79,3 +79,12 @@ def test_baseline_size_goldens_pin_the_fast_oracle(name):
     if fx['wav'].size:
         wav = orc.epilogue(r['samples'].T, 1024, True, False, 11000, 550, (int(fx['T']) - 1) * 275, 275)
         np.testing.assert_array_equal(wav.astype(np.float32), fx['wav'])
+
+
+def test_torch_cpu_loop_is_the_reference_loop():
+    """oracle/torch_cpu_loop.py (bench.py's `cpu_baseline`: the reference's op sequence on torch-CPU, timed on the GPU box where
+    /root/reference does not exist) reproduces the labels the unmodified reference produced -- same ops, same RNG consumption."""
+    from oracle import torch_cpu_loop as tl
+    fx = load_case('raw_peaky_b1_t24')
+    r = tl.run(fx['state_dict'], fx['mels'], 1500, 2, seed=int(fx['noise_seed']))
+    np.testing.assert_array_equal(r['labels'], fx['labels'].astype(np.int64)[:1500])

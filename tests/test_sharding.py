@@ -130,6 +130,9 @@ def test_bench_distributed_scaffolding_dry_run(tmp_path):
         if cfg == '3':
             assert d['dry_run_check'] == 'ok'
             assert d['value'] == pytest.approx(2 * 2 * 3 * 21 * 275 / (d['ms_per_step'] * 2 / 1e3) / 1e3, rel=1e-3)
+        else:   # the driver's SCALE command (config 1 at N > 1) also carries BASELINE configs[3] at that N
+            e3 = d['extra_configs']['3']
+            assert e3['n_gpus'] == 2 and e3['dry_run_check'] == 'ok' and 'RCCL' in e3['config']['workload']
 
 
 def test_bench_scaffolding_at_the_real_rank_count(tmp_path):

@@ -348,3 +348,45 @@ def test_the_reference_training_loop_body_runs_unchanged(name):
         ev = m(xt, mt)
     assert not ev.requires_grad and tuple(ev.shape) == tuple(y_hat.shape)
     print(f'\n[train {name}] unchanged loop body: loss {float(loss.detach()):.6f}, worst gradient sample error vs the reference digests {worst:.2e}')
+
+
+@pytest.mark.gpu
+def test_split_forward_backward_survive_a_batch_size_change_on_the_step_kernels():
+    """Round-3 advisor finding: on the per-step-kernel path (hipGraph replay) a forward-only call re-captured only the forward graphs
+    when (B, L) changed, and the following backward replayed the PREVIOUS problem's graph (stale grid, stale workspace pointers).
+    `y_hat = model(x, m); loss.backward()` at B = 6 and then at B = 3 -- the reference loop body when the loader's last batch is
+    short -- against the same B = 3 pass on the team kernels."""
+    import torch.nn.functional as F
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels
+    c = CASES['train_raw_peaky_b4_t5']
+    sd = make_state_dict(0, mode='RAW', variant='peaky', bits=10)
+    m = _model(c, sd)
+    dev = torch.device('cuda:0')
+    nat = m._native_handle()
+    T, hop = 2, 275
+
+    def one_pass(B, seed):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        lab = rng.integers(0, 1024, size=(B, T * hop + 1))
+        xt = torch.from_numpy((2.0 * lab[:, :-1] / 1023.0 - 1.0).astype(np.float32)).to(dev)
+        yt = torch.from_numpy(lab[:, 1:].astype(np.int64)).to(dev)
+        mt = torch.from_numpy(make_mels(seed, B, T + 4)).to(dev)
+        y_hat = m(xt, mt)
+        loss = F.cross_entropy(y_hat.transpose(1, 2).unsqueeze(-1), yt.unsqueeze(-1))
+        m.zero_grad()
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
+
+    m.train()
+    try:
+        nat.train_force_step_kernels(True)
+        one_pass(6, 11)                       # captures the graphs of the (6, L) problem
+        loss_s, g_s = one_pass(3, 12)         # forward re-captures; the backward must too
+        nat.train_force_step_kernels(False)
+        loss_t, g_t = one_pass(3, 12)         # the same pass on the persistent team kernels
+    finally:
+        nat.train_force_step_kernels(False)
+    assert abs(loss_s - loss_t) <= 2e-6 * abs(loss_t)
+    for k in g_t:
+        e = np.abs(g_s[k] - g_t[k]).max() / max(np.abs(g_t[k]).max(), 1e-12)
+        assert e <= 2e-3, (k, float(e))
