@@ -737,9 +737,10 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(19);
 
                 // ---------------- window 5: conditioning of the next step ----------------
-                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: C's fc3 outputs of all rows are in LDS
+                // (MOL: in front of B4b -- behind it the C waves only sample, 800 cycles, and then waited 775 at B5 for this)
                 if (t + 1 < bsteps) cond_step(t + 1);
                 PBW(17);
+                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: C's fc3 outputs of all rows are in LDS
                 __syncthreads();   // B5
                 PBW(23);
                 if ((t & 63) == 63) {

@@ -70,24 +70,26 @@ __device__ __forceinline__ void finish_n(const u64 *base, unsigned idx, unsigned
     }
 }
 
-// One exchange, one granule per thread, two staggered first looks: look A is issued right away (it catches the
-// case where every producer was early), look B `T2_STAGGER` sleeps later; A is examined when it returns, B only
-// if A came back incomplete, the bounded re-read loop only if B is incomplete too.
-#ifndef T2_DEFER_OUT
-#define T2_DEFER_OUT 0   // developer knob: 1 = a shadow wave stores a step's outputs one step later (measured round 4: 297 -> 293.5 ksamples/s, not kept)
-#endif
+// One exchange, one granule per thread.  Shipped (round 4): ONE look right behind the publish, then the bounded re-read loop.
+// Rounds 1-3 issued two staggered looks (A at once, B `T2_STAGGER` sleeps later) and meant to examine B only if A came back
+// incomplete -- but written as `return all_ok(A) ? A : finish(B)` the compiler merged the two results with a v_cndmask behind
+// `s_waitcnt vmcnt(0)`, so every exchange waited for look B as well; and because B could still be in flight on the way out, every
+// later reuse of its registers (among them the first instruction of the step loop) got a conservative vmcnt(0).  Measured in one
+// session (profiles/r04_team2_experiments.txt, ksamples/s at B = 1): round-3 code 300.5; two looks with B really examined late
+// (T2_LATE_B 1: every path's result pinned to its own load, B retired behind the exchange's barrier) 296 - 297 with T2_STAGGER 3,
+// 293 with 2, 303 with 5; one look (T2_LATE_B 2) 303; one look behind an s_sleep (T2_PRESLEEP 1 / 2 / 4) 304 / 303 / 295.  The
+// staggered second look buys nothing: a look that arrives before the data costs one more round trip whichever way it is issued.
 #ifndef T2_STAGGER
 #define T2_STAGGER 3
 #endif
-// Round 4: the caller owns look B's registers (`gb`) and RETIRES them behind the barrier that follows the exchange (retire_look).
-// Written as `return all_ok(A) ? A : finish(B)` the compiler merged the two results with a v_cndmask behind `s_waitcnt vmcnt(0)`:
-// every exchange waited for look B -- issued T2_STAGGER sleeps (~190 cycles) after look A -- even when A already carried the data,
-// 4 times per step on the serial chain.  The empty asm pins the A path's result to look A alone.
+#ifndef T2_DEFER_OUT
+#define T2_DEFER_OUT 0   // developer knob, see the merge at the end of the step
+#endif
 #ifndef T2_PRESLEEP
 #define T2_PRESLEEP 0   // developer knob: s_sleep units in front of the first look
 #endif
 #ifndef T2_LATE_B
-#define T2_LATE_B 2   // 2 = ONE look, then the re-read loop (shipped); 1 = two staggered looks, B retired late; 0 = the round-3 code (two looks, B always waited for)
+#define T2_LATE_B 2   // 2 = one look + re-read loop (shipped); 1 = two staggered looks, B examined only when A is stale; 0 = the round-3 code
 #endif
 __device__ __forceinline__ unsigned take_granule(const u64 *base, unsigned idx, unsigned tag, bool &dead, unsigned *err, unsigned code, u64 (&gb)[1]) {
     u64 ga[1];
@@ -733,11 +735,9 @@ __global__ void __launch_bounds__(T2_THREADS, 2) loop_team2_kernel(WrnnTeamArgs 
                 // found in the ISA; the same in loop_batch*.hip).
                 xfeed = x_new;
                 if (a.x_forced) { float v = a.x_forced[(size_t)t * a.n_rows + row]; asm volatile("" : "+v"(v)); xfeed = v; }
-                // The outputs of step t are stored one step LATER by a shadow wave of workgroup 0 (window 2 below; after the loop for the
-                // last step).  Stored here by thread 0, a critical wave, they cost the serial chain a store acknowledgement per step: the
-                // step loop opens with `s_waitcnt vmcnt(0)` (take_granule's second look may still be in flight when the first one is
-                // taken, so the compiler must assume pending loads wherever their registers are reused), and that wait also covered these
-                // two stores, issued a few instructions before it -- in the one workgroup whose x3 every other workgroup then waits for.
+                // T2_DEFER_OUT 1 (developer knob, NOT shipped): the outputs of step t stored one step later by a shadow wave of workgroup 0
+                // instead of by thread 0 here, to keep the store acknowledgements off the critical waves.  Measured: 297 -> 293.5
+                // ksamples/s -- the acknowledgements were never on the serial chain.
                 out_k = bk; out_x = x_new;
 #if !T2_DEFER_OUT
                 if (g == 0 && tid == 0) {

@@ -149,7 +149,7 @@ def test_config2_b64_sampled_batch_kernel_all_rows():
     assert m.last_timing['kernel'] in (_cabi.KERNEL_BATCH, _cabi.KERNEL_BATCH_CS)
     lab, smp = res['labels'].cpu().numpy(), res['samples'].cpu().numpy()          # (64, L)
     assert lab.shape == (B, T * 275)
-    _check_rows_raw('configs[2] B=64 T=41 philox, batch kernel, all rows', sd, mels, lab, smp, seed, list(range(B)), 16)
+    _check_rows_raw('configs[2] B=64 T=41 philox, all rows', sd, mels, lab, smp, seed, list(range(B)), 16)
     # all 64 rows are different utterances with different noise: no two label sequences coincide
     assert len({lab[i, :2000].tobytes() for i in range(B)}) == B
     np.testing.assert_array_equal(smp, 2.0 * lab.astype(np.float32) / np.float32(1023.0) - np.float32(1.0))
@@ -233,7 +233,7 @@ def test_config4_mol_b32_batch_kernel_all_rows():
     """configs[4]: MOL 9-bit, B=32, injected u_mix / u_log, T=41; the batch kernel (4 rows per team).  ALL 32 rows, every
     step: mixture index identical (near-tie rule) and the continuous sample within 2e-5 of the oracle started from the
     GPU's own previous sample."""
-    _mol_case(32, 41, list(range(32)), 'configs[4] MOL B=32 T=41, batch kernel')
+    _mol_case(32, 41, list(range(32)), 'configs[4] MOL B=32 T=41')
 
 
 def test_config4_mol_b32_t401_full_size_rows():

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in 1 2 4; do
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG:-rXX}/kt_c$c -o kt -- python $R/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs > $R/gpurun_out/prof_${TAG:-rXX}/kt_c${c}_stdout.log 2>&1
 done
-for c in 1 2; do
+for c in 1 2 4; do
   rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_${TAG:-rXX}/fetch_c$c -o fetch -- python $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs > $R/gpurun_out/prof_${TAG:-rXX}/fetch_c${c}_stdout.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG:-rXX}/write_c$c -o write -- python $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs > $R/gpurun_out/prof_${TAG:-rXX}/write_c${c}_stdout.log 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_BUSY_CYCLES -d $R/gpurun_out/prof_${TAG:-rXX}/sq_c$c -o sq -- python $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs > $R/gpurun_out/prof_${TAG:-rXX}/sq_c${c}_stdout.log 2>&1
