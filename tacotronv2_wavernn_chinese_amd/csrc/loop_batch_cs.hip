@@ -34,6 +34,21 @@
 #ifndef CS_GATHER
 #define CS_GATHER 0
 #endif
+#ifndef CS_SPLIT_WIN
+#define CS_SPLIT_WIN 1   // RAW, 8 rows per team: the winner of batch row wl + 4 is reduced by the S wave (window 5, behind its conditioning work)
+#endif
+#ifndef CS_SPRIO
+#define CS_SPRIO 1   // the S waves' h1' gather + meeting point run at the C waves' priority (+1 % at R = 4, nothing at R = 8)
+#endif
+#ifndef CS_NOISE_W1
+#define CS_NOISE_W1 (MODE == WRNN_MODE_RAW)   // the sampler's noise of a step is prepared in window 1 of that step (RAW: +0.7 % at R = 8; MOL: -0.6 %, stays in window 4 of the step before)
+#endif
+#ifndef CS_LATE_FOLD
+#define CS_LATE_FOLD 1   // the fold of a shadow product runs behind the barrier that ends the product's window
+#endif
+#ifndef CS_SSLEEP
+#define CS_SSLEEP 1   // s_sleep units between two sentinel looks
+#endif
 #ifndef CS_DELAY
 #define CS_DELAY 4
 #endif
@@ -78,18 +93,36 @@ constexpr int H_GH1R = 0, H_GH1Z = 1, H_GH1N = 2, H_CDX = 3, H_CDY = 4, H_CDZ = 
 // full look re-reads R x 4 KB per workgroup while the producers' stores queue behind those reads
 template <int NM>
 __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], bool &dead,
-                                          unsigned *err, unsigned code) {
+                                          unsigned *err, unsigned code, volatile int *seen = nullptr) {
 #if CS_GATHER == 0
     unsigned spins = 0;
     for (;;) {
         const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
         if (__all(sv.y == tag && sv.w == tag) || dead) break;
         if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
-        __builtin_amdgcn_s_sleep(1);
+#if CS_SSLEEP
+        __builtin_amdgcn_s_sleep(CS_SSLEEP);
+#endif
     }
 #elif CS_GATHER == 2
     __builtin_amdgcn_s_sleep(CS_DELAY);
+#elif CS_GATHER == 3
+    // two sentinel looks in flight, half a round trip apart: the arrival is noticed ~a quarter of a round trip after it happened instead of ~half
+    {
+        unsigned spins = 0;
+        u4v s0 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
+        for (;;) {
+            __builtin_amdgcn_s_sleep(CS_DELAY);
+            const u4v s1 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
+            if (__all(s0.y == tag && s0.w == tag) || dead) break;
+            __builtin_amdgcn_s_sleep(CS_DELAY);
+            s0 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
+            if (__all(s1.y == tag && s1.w == tag)) break;
+            if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+        }
+    }
 #endif
+    if (seen && (threadIdx.x & 63) == 0) *seen = (int)tag;   // "the data is there, my full look goes out now" (CS_LATE_H1 2: the S wave's look follows)
     const unsigned offs[1] = {soff};
     gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
 }
@@ -113,6 +146,8 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     typedef LayCS<NQ> L;
     constexpr int R = L::R, NM = LM::NM, SL = L::SL;
     constexpr int DG = NQ == 1 ? 2 : 1, DS = NQ == 1 ? 4 : 2, D3 = NQ == 1 ? 2 : 1;
+    // rows whose race a C wave finishes itself: RAW at 8 rows per team hands the second one (batch row wl + 4) to the S wave of its SIMD
+    constexpr int NBC = (MODE == WRNN_MODE_RAW && NQ == 2 && CS_SPLIT_WIN) ? 1 : NQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
     int *misc_i = (int *)(lds + L::L_MISC);
@@ -225,6 +260,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + 2u * (unsigned)(tl & 31)) * 4u);
 
     volatile int *tok = (volatile int *)(misc_i + 4 + wl);   // CS_YIELD: C wave wl -> S wave wl of the same SIMD: 1 = "in a dependent VALU chain, keep the matrix pipe free"
+    volatile int *tok2 = (volatile int *)(misc_i + 12 + wl);   // CS_LATE_H1 2: C wave wl -> S wave wl: epoch whose x2 has arrived (h1' was published with it)
     volatile int *sflag = (volatile int *)(misc_i + 8);         // CS_LATE_H1: S-wave meeting point (epoch of the H1 each wave has written)
     typedef int i4v __attribute__((ext_vector_type(4)));
     volatile i4v *sflag4 = (volatile i4v *)(misc_i + 8);
@@ -282,7 +318,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(0);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u);
+                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u, CS_LATE_H1 == 2 ? tok2 : nullptr);
                     PBW(1);
 #pragma unroll
                     for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
@@ -461,16 +497,16 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 }
                 PBW(20);
                 if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b
-                u4v gqa[NQ];
+                u4v gqa[NBC];
                 if (MODE == WRNN_MODE_RAW) {
                     const unsigned tg = epoch & 0x3fffffu;
                     unsigned spins = 0;
                     for (;;) {
 #pragma unroll
-                        for (int i = 0; i < NQ; ++i) gqa[i] = ld_pair(mrs, (unsigned)lane * 16u, (LM::G_PR + par * LM::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u);
+                        for (int i = 0; i < NBC; ++i) gqa[i] = ld_pair(mrs, (unsigned)lane * 16u, (LM::G_PR + par * LM::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u);
                         bool ok = true;
 #pragma unroll
-                        for (int i = 0; i < NQ; ++i) ok = ok && (gqa[i].y >> 10) == tg && (gqa[i].w >> 10) == tg;
+                        for (int i = 0; i < NBC; ++i) ok = ok && (gqa[i].y >> 10) == tg && (gqa[i].w >> 10) == tg;
                         if (__all(ok) || dead) break;
                         if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 26u); break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -481,14 +517,14 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 // workgroup 0 go out after the LAST row's value is in LDS: with the load and the stores inside the per-row code the
                 // compiler had to put an `s_waitcnt vmcnt(0)` in front of the second row -- workgroup 0, the one every other workgroup
                 // waits for at the next exchange, sat there until the first row's global stores were acknowledged (~500 cycles per row).
-                float xfv[NQ], xnv[NQ];
-                int labv[NQ];
+                float xfv[NBC], xnv[NBC];
+                int labv[NBC];
 #pragma unroll
-                for (int bi = 0; bi < NQ; ++bi) xfv[bi] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + frow[bi]] : 0.0f;
+                for (int bi = 0; bi < NBC; ++bi) xfv[bi] = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + frow[bi]] : 0.0f;
 #pragma unroll
-                for (int bi = 0; bi < NQ; ++bi) asm volatile("" : "+v"(xfv[bi]));   // waited for here, once
+                for (int bi = 0; bi < NBC; ++bi) asm volatile("" : "+v"(xfv[bi]));   // waited for here, once
 #pragma unroll
-                for (int bi = 0; bi < NQ; ++bi) {
+                for (int bi = 0; bi < NBC; ++bi) {
                     const int brow = wl + 4 * bi;
                     float x_new;
                     int lab;
@@ -524,7 +560,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 }
                 if (lane == 0 && g == 0) {
 #pragma unroll
-                    for (int bi = 0; bi < NQ; ++bi) {
+                    for (int bi = 0; bi < NBC; ++bi) {
                         if (t < fsteps[bi]) {   // a real row that has not reached its own length (ragged batch)
                             if (a.labels_out) a.labels_out[(size_t)frow[bi] * a.steps + t] = labv[bi];
                             a.samples_out[(size_t)frow[bi] * a.steps + t] = xnv[bi];
@@ -572,11 +608,13 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 }
             };
             // -log q of this thread's two classes for step ts (RAW) -> nz slots of parity `np` (see loop_batch.hip for the Philox block)
-            int frowS[NQ];   // rows whose sampler the C wave of this SIMD runs (MOL: their noise is prepared here)
+            int frowS[NQ], fstepsS[NQ];   // rows whose sampler the C wave of this SIMD runs (MOL: their noise is prepared here; RAW R = 8: row wl + 4 finished here)
 #pragma unroll
             for (int bi = 0; bi < NQ; ++bi) {
                 const int brow = wl + 4 * bi, s0 = batch * a.rpb + brow;
-                frowS[bi] = a.order[(brow < a.rpb && s0 < a.n_rows) ? s0 : a.n_rows - 1];
+                const bool rok = brow < a.rpb && s0 < a.n_rows;
+                frowS[bi] = a.order[rok ? s0 : a.n_rows - 1];
+                fstepsS[bi] = rok ? a.rows[frowS[bi]].steps : 0;
             }
             auto noise_step = [&](int64_t ts, unsigned np) {
                 if (MODE != WRNN_MODE_RAW) {
@@ -623,7 +661,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 hand[H_GH2R * SL] = cst[C_H2R * SL]; hand[H_GH2Z * SL] = cst[C_H2Z * SL]; hand[H_GH2N * SL] = cst[C_H2N * SL];
             }
             cond_step(0);
-            noise_step(0, (epoch + 1) & 1u);
+            if (!CS_NOISE_W1) noise_step(0, (epoch + 1) & 1u);
             __syncthreads();
 
             for (int64_t t = 0; t < bsteps; ++t) {
@@ -639,10 +677,34 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                     for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
                 }
+                // the sampler's noise of THIS step, while the C waves wait for x2 (an S wave has nothing else to do before B1; in window 4,
+                // behind the W_hh2 fold, it made the S waves late at B4)
+                if (CS_NOISE_W1) noise_step(t, par);
+                u4v gxe[1][NM];
+                if (CS_LATE_H1 == 2) {
+                    // the look goes out as soon as the C wave of this SIMD has seen x2 arrive (h1' was published in the same instant) and has
+                    // issued its own look: the port serves that one first, this one right behind it, and the data waits in registers for B1
+                    for (unsigned sp = 0; sp < 400000u && *tok2 != (int)epoch && !dead; ++sp) __builtin_amdgcn_s_sleep(1);
+                    const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
+                    gather_issue<NM, 1>(mrs, gvoff, offs, gxe);
+                }
                 PBW(2);
                 __syncthreads();   // B1
                 PBW(3);
-                if (CS_LATE_H1) {
+                if (CS_LATE_H1 == 2) {
+                    const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
+                    gather_vecs<NM, 1, true>(mrs, gvoff, offs, epoch, gxe, dead, a.err, 22u);
+                    PBW(1);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gxe[0][m].x), __uint_as_float(gxe[0][m].z)};
+                    if (lane == 0) sflag[wl] = (int)epoch;
+                    for (unsigned sp = 0; sp < 200000u; ++sp) {
+                        const i4v f = *sflag4;
+                        if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
+                    }
+                }
+                if (CS_LATE_H1 == 1) {
+                    if (CS_SPRIO) __builtin_amdgcn_s_setprio(3);   // developer knob: the gather + meeting point at the C waves' priority
                     // h1' is not needed before this wave's own W_hh1 product: fetched HERE, the S waves are never the last to reach B1 (they
                     // were: their 32 KB look ran beside the C waves' x2 look through the same 64 B/clk port) and the x2 look has the port
                     // to itself.  The four S waves then meet through LDS flags (s_barrier would need the C waves).
@@ -657,40 +719,50 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         const i4v f = *sflag4;
                         if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
                     }
+                    if (CS_SPRIO) __builtin_amdgcn_s_setprio(0);
                 }
 
-                // ---------------- window 2: gh1 of the next step = W_hh1 . h1' + b_hh1 ----------------
-                {
-                    f4 acc[3][NQ];
+                // ---------------- windows 2 - 4: gh1' = W_hh1 . h1' + b_hh1 and gh2' = W_hh2 . (x3 - x2) + b_hh2 of the next step ----------------
+                // The MFMAs of a product run in "its" window (they read H1 resp. Q / P, which the C waves overwrite at the end of the next
+                // one); its FOLD -- pure register work, ~700 cycles at 8 rows -- runs behind the barrier, at the start of the next window:
+                // with the fold in front of B2 the S waves were the last to arrive there (B2 wait of the C waves 390 cycles + a stretched
+                // x3 exchange), and the same at B3.  The hand-over slots are read by C a whole step later.
+                f4 acc1[3][NQ], acc2[3][NQ];
 #pragma unroll
-                    for (int gt = 0; gt < 3; ++gt)
+                for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
-                    // Between two slabs the S wave looks at the token of the C wave it shares the SIMD with: while C folds phase B and
-                    // evaluates the GRU2 gates (a dependent VALU chain; measured 2 270 cycles with this wave's MFMAs in the matrix pipe,
-                    // 1 050 without) it issues nothing.  During C's own MFMAs both keep issuing: two waves fill the pipe (4 cycles per MFMA).
-                    auto yield = [&]() { if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); } };
-                    mfma_gates<NQ, 3, false, DG, decltype(yield), 0, CS_YIELD != 0>(wv, vH1, acc, yield);
-                    PBW(7);
+                    for (int q = 0; q < NQ; ++q) { acc1[gt][q] = (f4){0.f, 0.f, 0.f, 0.f}; acc2[gt][q] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                auto fold1 = [&]() {
                     float gr = 0.f, gz = 0.f, gn = 0.f;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
+                        const float fr = fold_kp(acc1[0][q]), fz = fold_kp(acc1[1][q]), fn = fold_kp(acc1[2][q]);
                         if (q == 0 || my_rq == q) { gr = fr + cst[C_H1R * SL]; gz = fz + cst[C_H1Z * SL]; gn = fn + cst[C_H1N * SL]; }
                     }
                     if (primary) { hand[H_GH1R * SL] = gr; hand[H_GH1Z * SL] = gz; hand[H_GH1N * SL] = gn; }
+                };
+                auto fold2 = [&]() {
+                    float gr = 0.f, gz = 0.f, gn = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float fr = fold_kp(acc2[0][q]), fz = fold_kp(acc2[1][q]), fn = fold_kp(acc2[2][q]);
+                        if (q == 0 || my_rq == q) { gr = fr + cst[C_H2R * SL]; gz = fz + cst[C_H2Z * SL]; gn = fn + cst[C_H2N * SL]; }
+                    }
+                    if (primary) { hand[H_GH2R * SL] = gr; hand[H_GH2Z * SL] = gz; hand[H_GH2N * SL] = gn; }
+                };
+                {
+                    // Between two slabs the S wave can look at the token of the C wave it shares the SIMD with (CS_YIELD, developer knob;
+                    // measured and not shipped: the paused S wave reaches B2 late)
+                    auto yield = [&]() { if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); } };
+                    mfma_gates<NQ, 3, false, DG, decltype(yield), 0, CS_YIELD != 0>(wv, vH1, acc1, yield);
                 }
+                PBW(7);
+                if (!CS_LATE_FOLD) fold1();
                 PBW(8);
                 __syncthreads();   // B2
                 PBW(10);
-
-                // ---------------- window 3: gh2 of the next step = W_hh2 . (x3 - x2) + b_hh2 (gate n's weights from LDS) ----------------
+                if (CS_LATE_FOLD) fold1();
                 {
-                    f4 acc[3][NQ];
-#pragma unroll
-                    for (int gt = 0; gt < 3; ++gt)
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                     f4 xq[NQ], xp[NQ], wn = wnl[0];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
@@ -711,27 +783,22 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                             const float wr = wv[96 + 4 * S + e], wz = wv[128 + 4 * S + e];
 #pragma unroll
                             for (int q = 0; q < NQ; ++q) {
-                                acc[0][q] = mfma4(wr, b[q][e], acc[0][q]);
-                                acc[1][q] = mfma4(wz, b[q][e], acc[1][q]);
-                                acc[2][q] = mfma4(wcur[e], b[q][e], acc[2][q]);
+                                acc2[0][q] = mfma4(wr, b[q][e], acc2[0][q]);
+                                acc2[1][q] = mfma4(wz, b[q][e], acc2[1][q]);
+                                acc2[2][q] = mfma4(wcur[e], b[q][e], acc2[2][q]);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    float gr = 0.f, gz = 0.f, gn = 0.f;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const float fr = fold_kp(acc[0][q]), fz = fold_kp(acc[1][q]), fn = fold_kp(acc[2][q]);
-                        if (q == 0 || my_rq == q) { gr = fr + cst[C_H2R * SL]; gz = fz + cst[C_H2Z * SL]; gn = fn + cst[C_H2N * SL]; }
-                    }
-                    if (primary) { hand[H_GH2R * SL] = gr; hand[H_GH2Z * SL] = gz; hand[H_GH2N * SL] = gn; }
                 }
+                if (!CS_LATE_FOLD) fold2();
                 PBW(12);
                 __syncthreads();   // B3
                 PBW(14);
+                if (CS_LATE_FOLD) fold2();
 
                 // ---------------- window 4: sampling noise of the next step (C reads this step's parity in window 5) ----------------
-                if (t + 1 < bsteps) noise_step(t + 1, par ^ 1u);
+                if (!CS_NOISE_W1 && t + 1 < bsteps) noise_step(t + 1, par ^ 1u);
                 PBW(16);
                 __syncthreads();   // B4
                 PBW(19);
@@ -741,6 +808,38 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 if (t + 1 < bsteps) cond_step(t + 1);
                 PBW(17);
                 if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: C's fc3 outputs of all rows are in LDS
+                if (NBC < NQ) {
+                    // exchange 5 for batch row wl + 4 (RAW, 8 rows per team): the C wave of this SIMD finishes row wl meanwhile.  One row per
+                    // wave instead of two one after the other in the four C waves (1 130 -> ~600 cycles at the end of the serial chain).
+                    const int brow = wl + 4;
+                    const unsigned tg = epoch & 0x3fffffu;
+                    u4v gq;
+                    unsigned spins = 0;
+                    for (;;) {
+                        gq = ld_pair(mrs, (unsigned)lane * 16u, (LM::G_PR + par * LM::PRG + (unsigned)brow * 128u) * 8u);
+                        if (__all((gq.y >> 10) == tg && (gq.w >> 10) == tg) || dead) break;
+                        if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 28u); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    float xf = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + frowS[1]] : 0.0f;
+                    asm volatile("" : "+v"(xf));
+                    const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
+                    const bool pb = vb > va;   // equal scores: the lower slot = the lower class range wins
+                    const float best = pb ? vb : va;
+                    const int besti = (int)((pb ? gq.w : gq.y) & 1023u);
+                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
+                    const u64 ball = __ballot(best == mx);
+                    const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
+                    const int lab = __builtin_amdgcn_readlane(besti, src);
+                    const float x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
+                    if (lane == 0) {
+                        xn[brow] = a.x_forced ? xf : x_new;   // (:237)
+                        if (g == 0 && t < fstepsS[1]) {
+                            if (a.labels_out) a.labels_out[(size_t)frowS[1] * a.steps + t] = lab;
+                            a.samples_out[(size_t)frowS[1] * a.steps + t] = x_new;
+                        }
+                    }
+                }
                 __syncthreads();   // B5
                 PBW(23);
                 if ((t & 63) == 63) {
