@@ -41,7 +41,13 @@
 #define CS_SPRIO 1   // the S waves' h1' gather + meeting point run at the C waves' priority (+1 % at R = 4, nothing at R = 8)
 #endif
 #ifndef CS_NOISE_W1
-#define CS_NOISE_W1 (MODE == WRNN_MODE_RAW)   // the sampler's noise of a step is prepared in window 1 of that step (RAW: +0.7 % at R = 8; MOL: -0.6 %, stays in window 4 of the step before)
+#define CS_NOISE_W1 1   // the sampler's noise of a step is prepared in window 1 of that step (0: in window 4 of the step before)
+#endif
+#ifndef CS_FC3_SPLIT
+#define CS_FC3_SPLIT 1   // MOL: fc3 shared between the C and the S wave of a SIMD
+#endif
+#ifndef CS_COND_W4
+#define CS_COND_W4 (MODE == WRNN_MODE_MOL)   // MOL: the conditioning of the next step in window 4 (in window 5 the C waves waited for it at B4b: 780 cycles)
 #endif
 #ifndef CS_LATE_FOLD
 #define CS_LATE_FOLD 1   // the fold of a shadow product runs behind the barrier that ends the product's window
@@ -127,6 +133,52 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
     gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
 }
 
+// one set of 4 fc3 rows (A-operand image `w3s` in LDS: [8 slabs][64 lanes] f4) times the gathered fc2 outputs: the thread's folded logit
+template <int NQ, int D3>
+__device__ __forceinline__ float fc3_one_set(lds_cf4p w3s, lds_cf4p xv, int my_rq) {
+    constexpr int NP = NQ == 1 ? 2 : 1;
+    f4 acc[NP][NQ];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[p][q] = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 ring[D3][NQ], rwa[D3];
+#pragma unroll
+    for (int dd = 0; dd < D3; ++dd) {
+        rwa[dd] = w3s[dd * 64];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ring[dd][q] = xv[(q * 8 + dd) * 64];
+    }
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+        f4 b[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) b[q] = ring[S % D3][q];
+        const f4 wa = rwa[S % D3];
+        if (S + D3 < 8) {
+            rwa[S % D3] = w3s[(S + D3) * 64];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) ring[S % D3][q] = xv[(q * 8 + S + D3) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[e % NP][q] = mfma4(wa[e], b[q][e], acc[e % NP][q]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float lg = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        f4 s0 = acc[0][q];
+#pragma unroll
+        for (int p = 1; p < NP; ++p) s0 += acc[p][q];
+        const float f0 = fold_kp(s0);
+        if (q == 0 || my_rq == q) lg = f0;
+    }
+    return lg;
+}
+
 }  // namespace
 
 #define PBW(i)                                                                 \
@@ -147,6 +199,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     constexpr int R = L::R, NM = LM::NM, SL = L::SL;
     constexpr int DG = NQ == 1 ? 2 : 1, DS = NQ == 1 ? 4 : 2, D3 = NQ == 1 ? 2 : 1;
     // rows whose race a C wave finishes itself: RAW at 8 rows per team hands the second one (batch row wl + 4) to the S wave of its SIMD
+    constexpr bool FC3_SPLIT = MODE == WRNN_MODE_MOL && CS_FC3_SPLIT;
     constexpr int NBC = (MODE == WRNN_MODE_RAW && NQ == 2 && CS_SPLIT_WIN) ? 1 : NQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
@@ -412,7 +465,13 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 // ---------------- window 5: fc3 (:223) + sampler (:225-237) ----------------
                 {
                     float lg0 = 0.f, lg1 = 0.f;
-                    if (wg_has_fc3) {
+                    if (FC3_SPLIT) {
+                        // MOL: the 8 sets of four fc3 rows are shared between the two waves of a SIMD -- this wave evaluates classes 8 wl + iu,
+                        // the S wave 8 wl + iu + 4 (the fc3 image is in LDS, so either wave can): 32 MFMAs each, side by side, instead of 64 here
+                        lg0 = fc3_one_set<NQ, D3>(w3, vP, my_rq) + cst[C_B30 * SL];
+                        if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 < NC)
+                            a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0] = lg0;
+                    } else if (wg_has_fc3) {
                         constexpr int NP = NQ == 1 ? 2 : 1;
                         f4 acc[2][NP][NQ];
 #pragma unroll
@@ -492,7 +551,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                                        (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
                     } else {
                         // MOL: the wave's 8 fc3 outputs of every batch row -> LDS; wave w samples batch rows w, w + 4 behind the barrier
-                        if (primary) { lgt[rb * 32 + cls0] = lg0; lgt[rb * 32 + cls0 + 4] = lg1; }
+                        if (primary) { lgt[rb * 32 + cls0] = lg0; if (!FC3_SPLIT) lgt[rb * 32 + cls0 + 4] = lg1; }
                     }
                 }
                 PBW(20);
@@ -585,6 +644,17 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
             int cst_frame = -1000000;
             // conditioning {cI, v_r, v_z, v_n} of step ts for (unit, row) -> cd slots; per-frame constants -> their slots when the frame
             // changed.  The record is read where it is used (L1-resident: 128 bytes per (frame, unit)); nothing is carried in registers.
+            // per-frame constants (c2 r, z, n, c3, c4) of a new frame: read with the conditioning, written to their slots by frame_flush() -- at
+            // once, or (CS_COND_W4: the conditioning runs in window 4, where C still reads this frame's c4) behind barrier B4
+            float4 pc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float pc4 = 0.0f;
+            bool frame_pending = false;
+            auto frame_flush = [&]() {
+                if (frame_pending) {
+                    if (primary) { hand[H_C2R * SL] = pc2.x; hand[H_C2Z * SL] = pc2.y; hand[H_C2N * SL] = pc2.z; hand[H_C3 * SL] = pc2.w; hand[H_C4 * SL] = pc4; }
+                    frame_pending = false;
+                }
+            };
             auto cond_step = [&](int64_t ts) {
                 const int64_t pos = rw.start + ts;
                 const bool live = pos < a.total_len;
@@ -601,10 +671,11 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 const float cw = fmaf(rk4, ra5.w, fmaf(rk3, ra5.x, fmaf(rk2, ra4.y, fmaf(rk1, ra3.z, fmaf(rk0, ra2.w, ra0.w)))));
                 if (primary) { hand[H_CDX * SL] = cx; hand[H_CDY * SL] = cy; hand[H_CDZ * SL] = cz; hand[H_CDW * SL] = cw; }
                 if (fi != cst_frame) {
-                    const float4 c2 = r[6];
-                    const float c4 = recb[(size_t)fi * 512 * 32 + 28];
-                    if (primary) { hand[H_C2R * SL] = c2.x; hand[H_C2Z * SL] = c2.y; hand[H_C2N * SL] = c2.z; hand[H_C3 * SL] = c2.w; hand[H_C4 * SL] = c4; }
+                    pc2 = r[6];
+                    pc4 = recb[(size_t)fi * 512 * 32 + 28];
                     cst_frame = fi;
+                    frame_pending = true;
+                    if (!CS_COND_W4) frame_flush();
                 }
             };
             // -log q of this thread's two classes for step ts (RAW) -> nz slots of parity `np` (see loop_batch.hip for the Philox block)
@@ -661,6 +732,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 hand[H_GH2R * SL] = cst[C_H2R * SL]; hand[H_GH2Z * SL] = cst[C_H2Z * SL]; hand[H_GH2N * SL] = cst[C_H2N * SL];
             }
             cond_step(0);
+            frame_flush();
             if (!CS_NOISE_W1) noise_step(0, (epoch + 1) & 1u);
             __syncthreads();
 
@@ -799,13 +871,20 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 
                 // ---------------- window 4: sampling noise of the next step (C reads this step's parity in window 5) ----------------
                 if (!CS_NOISE_W1 && t + 1 < bsteps) noise_step(t + 1, par ^ 1u);
+                if (CS_COND_W4 && t + 1 < bsteps) cond_step(t + 1);   // the cd slots are read in phase A of the next step only
                 PBW(16);
                 __syncthreads();   // B4
                 PBW(19);
 
                 // ---------------- window 5: conditioning of the next step ----------------
                 // (MOL: in front of B4b -- behind it the C waves only sample, 800 cycles, and then waited 775 at B5 for this)
-                if (t + 1 < bsteps) cond_step(t + 1);
+                if (CS_COND_W4) frame_flush(); else if (t + 1 < bsteps) cond_step(t + 1);
+                if (FC3_SPLIT) {   // this wave's half of fc3 (see the C waves' window 5)
+                    const float lg1 = fc3_one_set<NQ, D3>(w3 + 8 * 64, vP, my_rq) + cst[C_B31 * SL];
+                    if (primary) lgt[rb * 32 + cls0 + 4] = lg1;
+                    if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 + 4 < NC)
+                        a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0 + 4] = lg1;
+                }
                 PBW(17);
                 if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: C's fc3 outputs of all rows are in LDS
                 if (NBC < NQ) {
