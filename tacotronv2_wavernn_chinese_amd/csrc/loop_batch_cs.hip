@@ -52,6 +52,9 @@
 #ifndef CS_LATE_FOLD
 #define CS_LATE_FOLD 1   // the fold of a shadow product runs behind the barrier that ends the product's window
 #endif
+#ifndef CS_EARLY_LOOK
+#define CS_EARLY_LOOK 8   // the full look goes out once this many of the sentinel slice's 64 lanes carry the tag (0 = all of them)
+#endif
 #ifndef CS_SSLEEP
 #define CS_SSLEEP 1   // s_sleep units between two sentinel looks
 #endif
@@ -104,7 +107,13 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
     unsigned spins = 0;
     for (;;) {
         const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
+#if CS_EARLY_LOOK
+        // developer knob: the full look goes out as soon as CS_EARLY_LOOK of the sentinel slice's 64 lanes carry the step's tag (the
+        // stragglers' granules land while it is in flight)
+        if (__builtin_popcountll(__ballot(sv.y == tag && sv.w == tag)) >= CS_EARLY_LOOK || dead) break;
+#else
         if (__all(sv.y == tag && sv.w == tag) || dead) break;
+#endif
         if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
 #if CS_SSLEEP
         __builtin_amdgcn_s_sleep(CS_SSLEEP);
