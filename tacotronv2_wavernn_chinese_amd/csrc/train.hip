@@ -709,8 +709,6 @@ static int train_impl(wrnn_handle *h, int phase, const wrnn_loop_params *w, cons
     if (do_fwd) T_TRY(hipMemsetAsync(h->err_dev, 0, 64, s));   // device error word of the team kernels (wrnn_sync_status)
     auto *fwd_k = H == 512 ? gru_fwd_step_kernel<512> : gru_fwd_step_kernel<0>;
     auto *bwd_k = H == 512 ? gru_bwd_step_kernel<512> : gru_bwd_step_kernel<0>;
-    T_TRY(hipFuncSetAttribute((const void *)fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-    T_TRY(hipFuncSetAttribute((const void *)bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     const dim3 sgrid(H / GR_UW, (B + 31) / 32);
     // The recurrences as ONE persistent team kernel each (train_team.hip) where that is possible: rnn_dims 512, 32-CU teams, all four
     // instantiations resident; otherwise the per-step kernels below, replayed from hipGraphs.
@@ -735,6 +733,10 @@ static int train_impl(wrnn_handle *h, int phase, const wrnn_loop_params *w, cons
         }
     }
     const bool use_team = st->team_checked == 1 && H == TEAM_H && !h->train_force_steps;
+    if (!use_team) {   // the per-step kernels' LDS sizes: only where they run (the attribute is per device: set per call, a host-side table write)
+        T_TRY(hipFuncSetAttribute((const void *)fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+        T_TRY(hipFuncSetAttribute((const void *)bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    }
     float *img = ws + oIMG;
     auto recur_team = [&](int i, bool bwd, const float *dHext) -> hipError_t {
         const Gru &q = gr[i];

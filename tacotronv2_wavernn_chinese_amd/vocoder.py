@@ -544,6 +544,7 @@ class _LoopTrainFn(torch.autograd.Function):
             st = torch.cuda.current_stream(dev).cuda_stream
             nat.train_step([p.data_ptr() for p in ps], [g.data_ptr() for g in grads], x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(),
                            y.data_ptr(), B, L, loss.data_ptr(), logits.data_ptr() if want_logits else 0, d_m.data_ptr(), d_a.data_ptr(), st)
+            model._train_generation = getattr(model, '_train_generation', 0) + 1   # the workspace now holds THIS pass (see _LoopForwardFn)
             if model.check_device_errors is True:
                 nat.sync_status(st)   # waits for the stream: a busy GPU / a timed-out team kernel raises here, not as a silent NaN
         ctx.save_for_backward(d_m, d_a, *grads)
@@ -574,6 +575,11 @@ class _LoopForwardFn(torch.autograd.Function):
             nat.train_forward([p.data_ptr() for p in ps], x.data_ptr(), mels_up.data_ptr(), aux.data_ptr(), B, L, logits.data_ptr(), st)
             if model.check_device_errors is True:
                 nat.sync_status(st)
+        # the activations of this pass live in the handle's ONE workspace: stamp the pass, so that a backward that comes after another
+        # training call on the model (a second forward, a validation batch through training_loss, gradient accumulation over two forwards)
+        # fails loudly instead of differentiating the other pass (round-3 advisor finding)
+        model._train_generation = getattr(model, '_train_generation', 0) + 1
+        ctx.generation = model._train_generation
         ctx.model = model
         ctx.save_for_backward(x, mels_up, aux, *ps)
         return logits
@@ -582,6 +588,10 @@ class _LoopForwardFn(torch.autograd.Function):
     def backward(ctx, d_logits):
         x, mels_up, aux, *ps = ctx.saved_tensors
         model = ctx.model
+        if getattr(model, '_train_generation', 0) != ctx.generation:
+            raise RuntimeError('WaveRNN: another training call on this model ran between this forward and its backward; the forward\'s '
+                               'activations (kept in the native handle\'s single workspace) are gone.  Call backward() before the next '
+                               'forward / training_loss, or use training_loss() (forward + backward in one native call).')
         nat = model._native_handle()
         dev = x.device
         B, L = x.shape

@@ -390,3 +390,25 @@ def test_split_forward_backward_survive_a_batch_size_change_on_the_step_kernels(
     for k in g_t:
         e = np.abs(g_s[k] - g_t[k]).max() / max(np.abs(g_t[k]).max(), 1e-12)
         assert e <= 2e-3, (k, float(e))
+
+
+@pytest.mark.gpu
+def test_backward_after_another_training_call_fails_loudly():
+    """The split pass keeps its activations in the handle's single workspace: `y1 = model(x1, m1); y2 = model(x2, m2); y1.sum().backward()`
+    would differentiate the SECOND pass.  The forward is stamped; the stale backward raises (round-3 advisor finding)."""
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels
+    c = CASES['train_raw_peaky_b4_t5']
+    sd = make_state_dict(0, mode='RAW', variant='peaky', bits=10)
+    m = _model(c, sd)
+    m.train()
+    dev = torch.device('cuda:0')
+    rng = np.random.Generator(np.random.PCG64(5))
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (3, 2 * 275)).astype(np.float32)).to(dev) for _ in range(2)]
+    ms = [torch.from_numpy(make_mels(70 + i, 3, 2 + 4)).to(dev) for i in range(2)]
+    y1 = m(xs[0], ms[0])
+    y2 = m(xs[1], ms[1])
+    with pytest.raises(RuntimeError, match='another training call'):
+        y1.sum().backward()
+    m.zero_grad()
+    y2.sum().backward()                      # the latest pass is still differentiable
+    assert all(p.grad is not None for k, p in m.named_parameters() if not k.startswith('upsample'))
