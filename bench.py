@@ -74,12 +74,12 @@ CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
            3: dict(mode='RAW', bits=10, batch=64, name='configs[3]')}
 # HBM bytes of the loop kernel per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md + WRITE_SIZE), keyed by (config, kernel); absent = not measured.  STATIC numbers.
-TRAFFIC_SOURCE = ('profiles/r04_rocprofv3_summary.txt (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh taken on the tree at commit 9e8c175, '
+TRAFFIC_SOURCE = ('profiles/r04_rocprofv3_summary.txt (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh taken on the tree at commit 782b7ac, '
                   'the shipped loop kernels -- not this run)')
-TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_390_738 + 1_979_317,              # fetch_c1 + write_c1, per segment launch (loop_team2_kernel)
-                            (2, 5): 1_798_196_352 + 330_086_176,          # fetch_c2 + write_c2: the one launch of 64 x 110 275 samples (loop_batch_cs_kernel<RAW, 2>)
-                            (3, 5): 1_798_196_352 + 330_086_176,
-                            (4, 5): 935_854_976 + 205_789_248}            # fetch_c4 + write_c4: 32 x 110 275 samples (loop_batch_cs_kernel<MOL, 1>)
+TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_390_821 + 1_979_317,              # fetch_c1 + write_c1, per segment launch (loop_team2_kernel)
+                            (2, 5): 1_798_203_904 + 421_802_272,          # fetch_c2 + write_c2: the one launch of 64 x 110 275 samples (loop_batch_cs_kernel<RAW, 2>)
+                            (3, 5): 1_798_203_904 + 421_802_272,
+                            (4, 5): 1_116_693_888 + 29_551_872}           # fetch_c4 + write_c4: 32 x 110 275 samples (loop_batch_cs_kernel<MOL, 1>)
 # What bounds the B=1 latency kernel: 4 dependent all-gathers among the 32 workgroups of one XCD per step.
 # bench_micro/handoff.hip measures one such round (512 granules published, polled with sc1 loads, written to LDS, 2
 # barriers, NO compute between rounds): profiles/r03_handoff_microbench.txt.
