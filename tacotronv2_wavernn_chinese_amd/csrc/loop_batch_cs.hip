@@ -132,10 +132,10 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
         for (;;) {
             __builtin_amdgcn_s_sleep(CS_DELAY);
             const u4v s1 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
-            if (__all(s0.y == tag && s0.w == tag) || dead) break;
+            if (__builtin_popcountll(__ballot(s0.y == tag && s0.w == tag)) >= (CS_EARLY_LOOK ? CS_EARLY_LOOK : 64) || dead) break;
             __builtin_amdgcn_s_sleep(CS_DELAY);
             s0 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
-            if (__all(s1.y == tag && s1.w == tag)) break;
+            if (__builtin_popcountll(__ballot(s1.y == tag && s1.w == tag)) >= (CS_EARLY_LOOK ? CS_EARLY_LOOK : 64)) break;
             if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
         }
     }
