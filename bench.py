@@ -68,6 +68,7 @@ COND_BYTES = 836                                        # conditioning row + sam
 FLOP_PER_SAMPLE = {'RAW': 8_668_160, 'MOL': 7_650_304}
 HBM_PEAK = 8.0e12                   # MI355X_MICROARCH.md: 8 TB/s spec
 F32_PEAK = 157.3e12                 # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+SCALE_LEG_TIMEOUT = float(os.environ.get('WRNN_BENCH_SCALE_LEG_TIMEOUT', '180'))   # seconds the configs[3] leg of an N > 1 run may take before the watchdog prints the headline without it
 CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
            2: dict(mode='RAW', bits=10, batch=64, name='configs[2]'),
            4: dict(mode='MOL', bits=9, batch=32, name='configs[4]'),
@@ -525,11 +526,25 @@ def main() -> int:
     # from / gathered on rank 0 over RCCL -- one line carries the weak B=1-per-GPU number and the throughput-mode number
     scale_extra = None
     if args.config == 1 and world > 1 and not args.no_extra_configs and args.batch == 0 and args.kernel == 'auto':
+        # The headline is measured; this leg must not be able to take it down.  Its scatter / gather over RCCL has run on one rank (GPU box)
+        # and on 2 / 8 gloo ranks (CPU) -- never on 8 real GPUs -- so a watchdog stands behind it: if the leg is not back within
+        # SCALE_LEG_TIMEOUT seconds, rank 0 prints the headline line with the leg marked as timed out and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0 and out is not None:
+                out['extra_configs'] = {'3': {'error': f'configs[3] leg did not return within {SCALE_LEG_TIMEOUT} s (watchdog); headline unaffected'}}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(SCALE_LEG_TIMEOUT, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             scale_extra = run_config(3, world=world, rank=rank, dev=dev, dry=dry, steps=2, warmup=1, frames=args.frames, batch=(2 if dry else 0),
                                      kernel_name='auto', copy_peak=None)
         except Exception as ex:   # every rank raises or none does (the collectives are symmetric); never sink the headline
             scale_extra = {'error': repr(ex)}
+        dog.cancel()
     if rank == 0 and out is not None:
         if scale_extra is not None:
             keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'roofline', 'config', 'data', 'dry_run_check', 'error')

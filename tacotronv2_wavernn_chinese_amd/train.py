@@ -117,7 +117,12 @@ def voc_train_loop(paths: VocPaths, model, loss_func: Optional[Callable], optimi
     reference's (:103-121): ``y_hat = model(x, m)``, the transpose / unsqueeze that fit torch's loss signatures, ``loss_func``.
     ``clip_grad_norm`` / ``checkpoint_every`` are ``hp.voc_clip_grad_norm`` / ``hp.voc_checkpoint_every``; ``at_checkpoint(model,
     test_set, step)`` stands where the reference calls ``gen_testset`` (:137-138); ``report`` receives the progress line
-    (``stream(msg)``, :145).  Returns the list of per-iteration losses of this call."""
+    (``stream(msg)``, :145).  Returns the list of per-iteration losses of this call.
+    Deferred device errors (``check_device_errors='deferred'``): ``training_status()`` raises AFTER ``optimizer.step()`` of the failing
+    iteration has run on whatever the step produced -- nothing corrupt reaches disk (no checkpoint is written behind a raised error), but the
+    in-memory parameters and Adam moments are then poisoned: restore the latest checkpoint (``restore_checkpoint``) before continuing, do
+    not just retry the iteration.
+    """
     device = next(model.parameters()).device
     for g in optimizer.param_groups:
         g['lr'] = lr
@@ -277,9 +282,16 @@ def main(argv=None):
         loss_func = F.cross_entropy
 
     def at_checkpoint(mod, test_set, step):       # gen_testset (dataset.py:18-43): vocode a few held-out mels next to the checkpoint
+        from .dsp import decode_mu_law, label_2_float, save_wav
+        k = step // 1000
+        batch_str = f'gen_batched_target{hp.voc_target}_overlap{hp.voc_overlap}' if hp.voc_gen_batched else 'gen_NOT_BATCHED'
         for i, (wav, mel) in enumerate(test_set[:hp.voc_gen_at_checkpoint], 1):
+            x = np.load(wav)                          # the quantised target (:28-37): decoded and kept next to the generated file, as the reference does
+            bits = 16 if hp.voc_mode == 'MOL' else hp.bits
+            x = decode_mu_law(x, 2 ** bits, from_labels=True) if (hp.mu_law and hp.voc_mode != 'MOL') else label_2_float(x.astype(np.float64), bits)
+            save_wav(x, paths.voc_output / f'{k}k_steps_{i}_target.wav')
             m = torch.from_numpy(np.load(mel).T.astype(np.float32)).unsqueeze(0)
-            mod.generate(m, str(paths.voc_output / f'{step // 1000}k_steps_{i}.wav'), hp.voc_gen_batched, hp.voc_target,
+            mod.generate(m, str(paths.voc_output / f'{k}k_steps_{i}_{batch_str}.wav'), hp.voc_gen_batched, hp.voc_target,
                          hp.voc_overlap, hp.mu_law)
 
     voc_train_loop(paths, model, loss_func, optimizer, WindowLoader(train, hp.voc_batch_size, **kw), test, hp.voc_lr, total,

@@ -154,3 +154,22 @@ def test_bench_scaffolding_at_the_real_rank_count(tmp_path):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 8 and d['dry_run_check'] == 'ok' and d['scaling'] == 'weak'
     assert d['value'] == pytest.approx(8 * 2 * 2 * 21 * 275 / (d['ms_per_step'] * 2 / 1e3) / 1e3, rel=1e-3)
+
+
+def test_the_scale_leg_cannot_take_the_headline_down(tmp_path):
+    """`bench.py --gpus 2` (config 1) attaches configs[3]; if that leg hangs -- its RCCL scatter / gather has never run on 8 real GPUs --
+    a watchdog prints the headline line without it and every rank leaves.  Here the watchdog is made to fire at once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['WRNN_BENCH_SCALE_LEG_TIMEOUT'] = '0.001'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--cpu-dry-run', '--config', '1', '--steps', '2', '--warmup', '1',
+                        '--frames', '21'], capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, (r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0
+    assert 'watchdog' in d['extra_configs']['3']['error']
