@@ -52,6 +52,9 @@
 #ifndef CS_LATE_FOLD
 #define CS_LATE_FOLD 1   // the fold of a shadow product runs behind the barrier that ends the product's window
 #endif
+#ifndef CS_THROTTLE
+#define CS_THROTTLE 0
+#endif
 #ifndef CS_DIAG
 #define CS_DIAG 0   // TIMING DIAGNOSTIC ONLY (wrong results): bit 0 = the S waves skip the W_hh1 MFMAs, bit 1 = the W_hh2 MFMAs
 #endif
@@ -840,8 +843,11 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 {
                     // Between two slabs the S wave can look at the token of the C wave it shares the SIMD with (CS_YIELD, developer knob;
                     // measured and not shipped: the paused S wave reaches B2 late)
-                    auto yield = [&]() { if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); } };
-                    if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : CS_DGS), decltype(yield), 0, CS_YIELD != 0>(wv, vH1, acc1, yield);
+                    auto yield = [&]() {
+                        if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); }
+                        if (CS_THROTTLE) __builtin_amdgcn_s_sleep(CS_THROTTLE);   // developer knob: a gap between the slabs of a shadow product
+                    };
+                    if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : CS_DGS), decltype(yield), 0, (CS_YIELD != 0 || CS_THROTTLE != 0)>(wv, vH1, acc1, yield);
                 }
                 PBW(7);
                 if (!CS_LATE_FOLD) fold1();
@@ -855,6 +861,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
 #pragma unroll
                     for (int S = 0; S < 8; ++S) {
+                        if (CS_THROTTLE) __builtin_amdgcn_s_sleep(CS_THROTTLE);
                         f4 b[NQ];
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
