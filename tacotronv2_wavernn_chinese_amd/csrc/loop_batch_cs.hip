@@ -805,10 +805,12 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                     for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
                     if (lane == 0) sflag[wl] = (int)epoch;
+                    PBW(5);   // h1' written to LDS
                     for (unsigned sp = 0; sp < 200000u; ++sp) {
                         const i4v f = *sflag4;
                         if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
                     }
+                    PBW(6);   // the four S waves have met
                     if (CS_SPRIO) __builtin_amdgcn_s_setprio(0);
                 }
 
