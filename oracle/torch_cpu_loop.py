@@ -68,30 +68,24 @@ def run(state_dict: Dict[str, np.ndarray], mels: np.ndarray, steps: int, threads
             h1 = torch.zeros(B, rnn_dims)
             h2 = torch.zeros(B, rnn_dims)
             x = torch.zeros(B, 1)
-            d = aux_dims
-            aux_split = [aux[:, :, d * i:d * (i + 1)] for i in range(4)]
+            # the four aux slices the layers are conditioned on (:198-199), per step below: a[k][:, i, :]
+            a = [aux[:, :, aux_dims * k:aux_dims * (k + 1)] for k in range(4)]
             t1 = time.perf_counter()
+            feed = x
             for i in range(min(int(steps), L)):
                 if (i & 31) == 0 and time.perf_counter() - t1 > max_seconds:
                     break
-                m_t = up[:, i, :]
-                a1_t, a2_t, a3_t, a4_t = (a[:, i, :] for a in aux_split)
-                x = torch.cat([x, m_t, a1_t], dim=1)
-                x = I(x)
-                h1 = rnn1(x, h1)
-                x = x + h1
-                inp = torch.cat([x, a2_t], dim=1)
-                h2 = rnn2(inp, h2)
-                x = x + h2
-                x = torch.cat([x, a3_t], dim=1)
-                x = F.relu(fc1(x))
-                x = torch.cat([x, a4_t], dim=1)
-                x = F.relu(fc2(x))
-                logits = fc3(x)
-                posterior = F.softmax(logits, dim=1)
-                label = torch.distributions.Categorical(posterior).sample()
+                v = I(torch.cat((feed, up[:, i, :], a[0][:, i, :]), dim=1))          # :203-209
+                h1 = rnn1(v, h1)                                                    # :210-211
+                v = v + h1
+                h2 = rnn2(torch.cat((v, a[1][:, i, :]), dim=1), h2)                 # :213-214
+                v = v + h2
+                v = F.relu(fc1(torch.cat((v, a[2][:, i, :]), dim=1)))               # :216-218
+                v = F.relu(fc2(torch.cat((v, a[3][:, i, :]), dim=1)))               # :219-221
+                probs = F.softmax(fc3(v), dim=1)                                    # :223, :231
+                label = torch.distributions.Categorical(probs).sample()             # :233-234 (= torch.multinomial)
                 out_labels.append(label)
-                x = (2 * label.float() / (n_classes - 1.) - 1.).unsqueeze(-1)
+                feed = (2 * label.float() / (n_classes - 1.) - 1.).unsqueeze(-1)    # :235-237
             t2 = time.perf_counter()
         return dict(labels=torch.stack(out_labels).numpy(), loop_seconds=t2 - t1, prologue_seconds=t1 - t0, steps=len(out_labels), threads=threads)
     finally:
