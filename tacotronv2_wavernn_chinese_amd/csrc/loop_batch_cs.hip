@@ -55,6 +55,9 @@
 #ifndef CS_THROTTLE
 #define CS_THROTTLE 0
 #endif
+#ifndef CS_ROT
+#define CS_ROT 0
+#endif
 #ifndef CS_DIAG
 #define CS_DIAG 0   // TIMING DIAGNOSTIC ONLY (wrong results): bit 0 = the S waves skip the W_hh1 MFMAs, bit 1 = the W_hh2 MFMAs
 #endif
@@ -109,9 +112,33 @@ constexpr int H_GH1R = 0, H_GH1Z = 1, H_GH1N = 2, H_CDX = 3, H_CDY = 4, H_CDZ = 
 
 // sentinel first, then everything: a C / S wave has nothing to do between its publish and this gather, and a poll that opens with a
 // full look re-reads R x 4 KB per workgroup while the producers' stores queue behind those reads
+// CS_ROT (developer knob): register m of a thread holds slice (m + rot) & (NM - 1): the workgroups / waves of a team start their look at
+// different slices, so that at any instant their requests are spread over the L2 channels instead of all asking for slice 0 first
+template <int NM>
+__device__ __forceinline__ void gather_rot(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], unsigned rot, bool &dead,
+                                           unsigned *err, unsigned code) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) ok = ok && g[0][m].y == tag && g[0][m].w == tag;
+        if (__all(ok) || dead) break;
+        for (;;) {
+            if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+            __builtin_amdgcn_s_sleep(1);
+            const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
+            if (__all(sv.y == tag && sv.w == tag)) break;
+        }
+        if (dead) break;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
+    }
+}
 template <int NM>
 __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], bool &dead,
-                                          unsigned *err, unsigned code, volatile int *seen = nullptr) {
+                                          unsigned *err, unsigned code, volatile int *seen = nullptr, unsigned rot = 0) {
 #if CS_GATHER == 0
     unsigned spins = 0;
     for (;;) {
@@ -147,8 +174,12 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
     }
 #endif
     if (seen && (threadIdx.x & 63) == 0) *seen = (int)tag;   // "the data is there, my full look goes out now" (CS_LATE_H1 2: the S wave's look follows)
+#if CS_ROT
+    gather_rot<NM>(rs, voff, soff, tag, g, rot, dead, err, code);
+#else
     const unsigned offs[1] = {soff};
     gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
+#endif
 }
 
 // one set of 4 fc3 rows (A-operand image `w3s` in LDS: [8 slabs][64 lanes] f4) times the gathered fc2 outputs: the thread's folded logit
@@ -286,6 +317,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const bool wg_has_fc3 = MODE == WRNN_MODE_MOL || 32 * g < NC;
     const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
     const unsigned gvoff = (unsigned)tl * 16u;
+    const unsigned rot = CS_ROT ? (unsigned)__builtin_amdgcn_readfirstlane((g * 5 + wave * 3) & (NM - 1)) : 0u;   // CS_ROT: where this wave's looks start
     // compact slot index of this thread's (unit, row): duplicates (kp2 >= NQ) read their primary lane's entry (an LDS broadcast)
     const int ci = (wl * 4 + rho) * (4 * NQ) + my_rq * 4 + j;
 
@@ -389,10 +421,10 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(0);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u, CS_LATE_H1 == 2 ? tok2 : nullptr);
+                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u, CS_LATE_H1 == 2 ? tok2 : nullptr, rot);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(0 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
                 PBW(2);
                 __syncthreads();   // B1
@@ -426,9 +458,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(6);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X3 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 23u);
+                    gather_sf<NM>(mrs, gvoff, (LM::G_X3 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 23u, nullptr, rot);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(1 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(1 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
                 PBW(9);
                 __syncthreads();   // B2
@@ -449,9 +481,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(11);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 24u);
+                    gather_sf<NM>(mrs, gvoff, (LM::G_F1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 24u, nullptr, rot);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(2 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
                 PBW(13);
                 __syncthreads();   // B3
@@ -472,9 +504,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(15);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u);
+                    gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u, nullptr, rot);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(0 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
                 PBW(18);
                 __syncthreads();   // B4
@@ -765,7 +797,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     gather_sf<NM>(mrs, gvoff, (LM::G_H1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 22u);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(2 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
                 // the sampler's noise of THIS step, while the C waves wait for x2 (an S wave has nothing else to do before B1; in window 4,
                 // behind the W_hh2 fold, it made the S waves late at B4)
@@ -800,10 +832,11 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     // to itself.  The four S waves then meet through LDS flags (s_barrier would need the C waves).
                     u4v gx[1][NM];
                     const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
-                    gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
+                    if (CS_ROT) gather_rot<NM>(mrs, gvoff, offs[0], epoch, gx, rot, dead, a.err, 22u);
+                    else gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(2 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                     if (lane == 0) sflag[wl] = (int)epoch;
                     PBW(5);   // h1' written to LDS
                     for (unsigned sp = 0; sp < 200000u; ++sp) {
