@@ -27,7 +27,7 @@
 
 #define CS_THREADS 512
 // developer knobs (tools/build_variant.sh): CS_PRIO 1 = the C waves run at s_setprio 3; CS_GATHER 0 = sentinel first, 1 = a full look at once,
-// 2 = s_sleep(CS_DELAY) and then a full look (both with the sentinel fall-back); CS_YIELD 1 = an S wave issues no MFMA while the C wave of its SIMD folds / evaluates gates (token in LDS)
+// 2 = s_sleep(CS_DELAY) and then a full look (both with the sentinel fall-back); CS_YIELD 1 = an S wave issues no MFMA while the C wave of its SIMD folds / evaluates gates (token in LDS), 2 = while that C wave's x3 / f1 data look is in flight
 #ifndef CS_PRIO
 #define CS_PRIO 1
 #endif
@@ -55,11 +55,39 @@
 #ifndef CS_THROTTLE
 #define CS_THROTTLE 0
 #endif
+#ifndef CS_PROF_ROUNDS
+#define CS_PROF_ROUNDS 0  // with CS_PROF_SPLIT: marker 8 of the C wave = 1000 x the data looks per step of ONE exchange (17 = x2, 7 = x3, 12 = f1, 16 = f2)
+#endif
+#ifndef CS_PROF_FINE
+#define CS_PROF_FINE 0
+#endif
+#ifndef CS_PROF_SPLIT
+#define CS_PROF_SPLIT 0   // instrumented build: the C waves' exchanges are reported in two parts (sentinel wait: markers 17 / 7 / 12 / 16, the rest under the usual marker)
+#endif
+#if CS_PROF_SPLIT
+#define GSF_DECL unsigned ts_ = 0, rnd_ = 0, fine_[2] = {0, 0}
+#define GSF_TS , PROF ? &ts_ : nullptr, PROF ? &rnd_ : nullptr, (PROF && CS_PROF_FINE) ? fine_ : nullptr
+// CS_PROF_FINE = marker of ONE exchange (7 = x3, 12 = f1, 16 = f2): only that exchange is split, and its data look in three parts -- marker 8: sentinel seen -> first
+// load back, marker 17: first -> all loads back and checked; the exchange's usual marker keeps the LDS write
+#define GSF_ACC(i)                                                                                              \
+    do {                                                                                                        \
+        if (PROF && CS_PROF_FINE == (i)) { PBS(i, ts_); PBS(8, fine_[0]); PBS(17, fine_[1]); }                  \
+        else if (!CS_PROF_FINE) PBS(i, ts_);                                                                    \
+        if (PROF && CS_PROF_ROUNDS == (i) && lane == 0 && wl == 0) prof_lds[8] += rnd_;                         \
+    } while (0)
+#else
+#define GSF_DECL
+#define GSF_TS
+#define GSF_ACC(i)
+#endif
+#ifndef CS_PROF_WG
+#define CS_PROF_WG 0   // instrumented build: the workgroup (arrival rank inside its team) whose wave 0 / wave 4 are reported
+#endif
 #ifndef CS_ROT
 #define CS_ROT 0
 #endif
 #ifndef CS_DIAG
-#define CS_DIAG 0   // TIMING DIAGNOSTIC ONLY (wrong results): bit 0 = the S waves skip the W_hh1 MFMAs, bit 1 = the W_hh2 MFMAs
+#define CS_DIAG 0   // TIMING DIAGNOSTIC ONLY (wrong results): bit 0 = the S waves skip the W_hh1 MFMAs, bit 1 = the W_hh2 MFMAs; 4 / 8 and 16 / 32 / 64: see diag_skip, diag_gates
 #endif
 #ifndef CS_DGS
 #define CS_DGS 1   // slabs of B operands the S waves' W_hh1 loop requests ahead at 8 rows per team
@@ -114,16 +142,55 @@ constexpr int H_GH1R = 0, H_GH1Z = 1, H_GH1N = 2, H_CDX = 3, H_CDY = 4, H_CDZ = 
 // full look re-reads R x 4 KB per workgroup while the producers' stores queue behind those reads
 // CS_ROT (developer knob): register m of a thread holds slice (m + rot) & (NM - 1): the workgroups / waves of a team start their look at
 // different slices, so that at any instant their requests are spread over the L2 channels instead of all asking for slice 0 first
+// CS_DIAG 4 / 8 (timing diagnostics, wrong results): a look fetches 3/4 / 1/2 of its slices (the sentinel slice NM - 1 is always among them)
+__device__ __forceinline__ constexpr bool diag_skip(int m) { return CS_DIAG == 4 ? (m & 3) == 2 : CS_DIAG == 8 ? (m & 1) == 0 : false; }
+// CS_DIAG 16 / 32 / 64 (timing diagnostics, wrong results): the S waves' W_hh1 product with (16) two v_fma per MFMA instead of the MFMA, (32) its B operands
+// read from LDS once in front of the loop instead of slab by slab, (64) one A register for all MFMAs -- which property of the product slows the C wave's look?
+template <int NQ, int V>
+__device__ __forceinline__ void diag_gates(const float *w, lds_cf4p xv, f4 (&acc)[3][NQ]) {
+    f4 b0[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) b0[q] = xv[(q * 8) * 64];
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+        f4 b[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) b[q] = V == 32 ? b0[q] : xv[(q * 8 + S) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) {
+                const float wa = V == 64 ? w[0] : w[gt * 32 + 4 * S + e];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (V == 16) { acc[gt][q].x = fmaf(wa, b[q][e], acc[gt][q].x); acc[gt][q].y = fmaf(wa, b[q][e], acc[gt][q].y); }
+                    else acc[gt][q] = mfma4(wa, b[q][e], acc[gt][q]);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 template <int NM>
 __device__ __forceinline__ void gather_rot(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], unsigned rot, bool &dead,
-                                           unsigned *err, unsigned code) {
+                                           unsigned *err, unsigned code, unsigned *rounds = nullptr, unsigned *fine = nullptr) {
 #pragma unroll
-    for (int m = 0; m < NM; ++m) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
+    for (int m = 0; m < NM; ++m)
+        if (!diag_skip(m)) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
+    if (fine) {   // instrumented build (CS_PROF_FINE): when the FIRST load of the data look is back
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NM - 1) : "memory");
+        fine[0] = (unsigned)__builtin_readcyclecounter();
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+        if (diag_skip(m)) g[0][m] = g[0][CS_DIAG == 4 ? m - 1 : (m | 1)];
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
         for (int m = 0; m < NM; ++m) ok = ok && g[0][m].y == tag && g[0][m].w == tag;
+        if (rounds) *rounds += 1000u;   // instrumented build: data looks of this exchange, x 1000
+        if (fine) fine[1] = (unsigned)__builtin_readcyclecounter();   // ... and when all of them are back and checked
         if (__all(ok) || dead) break;
         for (;;) {
             if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
@@ -133,12 +200,16 @@ __device__ __forceinline__ void gather_rot(__amdgpu_buffer_rsrc_t rs, unsigned v
         }
         if (dead) break;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
+        for (int m = 0; m < NM; ++m)
+            if (!diag_skip(m)) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+            if (diag_skip(m)) g[0][m] = g[0][CS_DIAG == 4 ? m - 1 : (m | 1)];
     }
 }
 template <int NM>
 __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], bool &dead,
-                                          unsigned *err, unsigned code, volatile int *seen = nullptr, unsigned rot = 0) {
+                                          unsigned *err, unsigned code, volatile int *seen = nullptr, unsigned rot = 0, unsigned *sent_cyc = nullptr, unsigned *rounds = nullptr, unsigned *fine = nullptr) {
 #if CS_GATHER == 0
     unsigned spins = 0;
     for (;;) {
@@ -173,9 +244,10 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
         }
     }
 #endif
+    if (sent_cyc) *sent_cyc = (unsigned)__builtin_readcyclecounter();   // instrumented build: the sentinel wait ends here, the data look starts
     if (seen && (threadIdx.x & 63) == 0) *seen = (int)tag;   // "the data is there, my full look goes out now" (CS_LATE_H1 2: the S wave's look follows)
-#if CS_ROT
-    gather_rot<NM>(rs, voff, soff, tag, g, rot, dead, err, code);
+#if CS_ROT || CS_DIAG >= 4 || CS_PROF_ROUNDS || CS_PROF_FINE
+    gather_rot<NM>(rs, voff, soff, tag, g, rot, dead, err, code, rounds, fine);
 #else
     const unsigned offs[1] = {soff};
     gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
@@ -238,6 +310,15 @@ __device__ __forceinline__ float fc3_one_set(lds_cf4p w3s, lds_cf4p xv, int my_r
             __builtin_amdgcn_sched_barrier(0);                                 \
             if (lane == 0 && wl == 0) prof_lds[(wave >> 2) * 24 + (i)] += now_ - prof_last; \
             prof_last = now_;                                                  \
+        }                                                                      \
+    } while (0)
+
+// instrumented build: the part of an exchange up to the stamp `ts` (taken inside gather_sf, behind the sentinel wait) goes to marker i
+#define PBS(i, ts)                                                             \
+    do {                                                                       \
+        if (PROF) {                                                            \
+            if (lane == 0 && wl == 0) prof_lds[(wave >> 2) * 24 + (i)] += (ts) - prof_last; \
+            prof_last = (ts);                                                  \
         }                                                                      \
     } while (0)
 
@@ -421,7 +502,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(0);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u, CS_LATE_H1 == 2 ? tok2 : nullptr, rot);
+                    GSF_DECL;
+                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u, CS_LATE_H1 == 2 ? tok2 : nullptr, rot GSF_TS);
+                    GSF_ACC(17);
                     PBW(1);
 #pragma unroll
                     for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(0 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
@@ -438,7 +521,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                     mfma_gates<NQ, 3, false, DG>(wv, vP, acc, NoMid());
-                    if (CS_YIELD && lane == 0) *tok = 1;   // the fold and the gates are a dependent VALU chain: the shadow wave's MFMAs wait
+                    if (CS_YIELD == 1 && lane == 0) *tok = 1;   // the fold and the gates are a dependent VALU chain: the shadow wave's MFMAs wait
                     PBW(4);
                     float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -453,12 +536,15 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     h2 = (1.0f - zg) * ng + zg * h2;
                     const float x3 = x2own + h2;
                     if (primary) st_granule(mail, LM::G_X3 + par * LM::RG + mb_own, epoch, __float_as_uint(x3));
-                    if (CS_YIELD && lane == 0) *tok = 0;
+                    if (CS_YIELD == 1 && lane == 0) *tok = 0;
                 }
                 PBW(6);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X3 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 23u, nullptr, rot);
+                    GSF_DECL;
+                    gather_sf<NM>(mrs, gvoff, (LM::G_X3 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 23u, CS_YIELD == 2 ? tok : nullptr, rot GSF_TS);
+                    if (CS_YIELD == 2 && lane == 0) *tok = 0;   // the look is back: the shadow wave's MFMAs go on
+                    GSF_ACC(7);
 #pragma unroll
                     for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(1 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
@@ -481,7 +567,10 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(11);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 24u, nullptr, rot);
+                    GSF_DECL;
+                    gather_sf<NM>(mrs, gvoff, (LM::G_F1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 24u, CS_YIELD == 2 ? tok : nullptr, rot GSF_TS);
+                    if (CS_YIELD == 2 && lane == 0) *tok = 0;
+                    GSF_ACC(12);
 #pragma unroll
                     for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(2 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
@@ -504,7 +593,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(15);
                 {
                     u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u, nullptr, rot);
+                    GSF_DECL;
+                    gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u, nullptr, rot GSF_TS);
+                    GSF_ACC(16);
 #pragma unroll
                     for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(0 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
                 }
@@ -832,7 +923,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     // to itself.  The four S waves then meet through LDS flags (s_barrier would need the C waves).
                     u4v gx[1][NM];
                     const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
-                    if (CS_ROT) gather_rot<NM>(mrs, gvoff, offs[0], epoch, gx, rot, dead, a.err, 22u);
+                    if (CS_ROT || CS_DIAG >= 4) gather_rot<NM>(mrs, gvoff, offs[0], epoch, gx, rot, dead, a.err, 22u);
                     else gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
                     PBW(1);
 #pragma unroll
@@ -882,7 +973,8 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); }
                         if (CS_THROTTLE) __builtin_amdgcn_s_sleep(CS_THROTTLE);   // developer knob: a gap between the slabs of a shadow product
                     };
-                    if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : CS_DGS), decltype(yield), 0, (CS_YIELD != 0 || CS_THROTTLE != 0)>(wv, vH1, acc1, yield);
+                    if (CS_DIAG & 112) diag_gates<NQ, (CS_DIAG & 112)>(wv, vH1, acc1);
+                    else if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : CS_DGS), decltype(yield), 0, (CS_YIELD != 0 || CS_THROTTLE != 0)>(wv, vH1, acc1, yield);
                 }
                 PBW(7);
                 if (!CS_LATE_FOLD) fold1();
@@ -896,6 +988,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
 #pragma unroll
                     for (int S = 0; S < 8; ++S) {
+                        if (CS_YIELD == 2) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); }
                         if (CS_THROTTLE) __builtin_amdgcn_s_sleep(CS_THROTTLE);
                         f4 b[NQ];
 #pragma unroll
@@ -987,7 +1080,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
         }
         __syncthreads();
     }
-    if (PROF && a.prof && lane == 0 && wl == 0 && g == 0 && team == 0) {   // reported as "wave 0" (C) and "wave 4" (S)
+    if (PROF && a.prof && lane == 0 && wl == 0 && g == CS_PROF_WG && team == 0) {   // reported as "wave 0" (C) and "wave 4" (S)
         for (int i = 0; i < 24; ++i) a.prof[wave * WRNN_PROF_SLOTS + i] += prof_lds[(wave >> 2) * 24 + i];
     }
 }
