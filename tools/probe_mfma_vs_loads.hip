@@ -32,7 +32,10 @@ __global__ __launch_bounds__(512) void probe(unsigned *blk, unsigned *out_cyc, u
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         out_busy[gridDim.x * 8 + wave] = hw;
     }
-    for (int i = tid; i < 64 * 8; i += 512) ldsb[i] = (f4){seed, seed, seed, seed};
+    for (int i = tid; i < 64 * 8; i += 512) {   // operands with busy mantissas (seed = 1: constants)
+        const float r0 = seed == 1.0f ? 1.0f : __uint_as_float(0x3f000000u | ((unsigned)(i * 2654435761u) >> 9));
+        ldsb[i] = (f4){r0, r0 * 1.37f, r0 * 0.71f, r0 * 1.93f};
+    }
     __syncthreads();
     if (wave < 4) {
         __builtin_amdgcn_s_setprio(3);   // as the C waves of loop_batch_cs.hip
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(512) void probe(unsigned *blk, unsigned *out_cyc, u
         float wreg[96];   // mode 6: resident "weights", as the S waves of loop_batch_cs.hip
         if (MODE == 6) {
 #pragma unroll
-            for (int i = 0; i < 96; ++i) { wreg[i] = seed * (float)(i + 1) + lane; asm volatile("" : "+v"(wreg[i])); }
+            for (int i = 0; i < 96; ++i) { wreg[i] = seed == 1.0f ? (float)(i + 1) + lane : __uint_as_float(0x3f000000u | ((unsigned)((i * 64 + lane) * 2246822519u) >> 9)); asm volatile("" : "+v"(wreg[i])); }
         }
         float fa[12];
 #pragma unroll
@@ -134,12 +137,12 @@ __global__ __launch_bounds__(512) void probe(unsigned *blk, unsigned *out_cyc, u
 }
 
 template <int MODE, bool BIG = false>
-static void run(const char *what, int per_iter, unsigned *blk, unsigned *d_cyc, unsigned *d_busy, int wgs, int sync, int pub) {
+static void run(const char *what, int per_iter, unsigned *blk, unsigned *d_cyc, unsigned *d_busy, int wgs, int sync, int pub, float seed = 1.0f) {
     CHECK(hipMemset(d_cyc, 0, wgs * 4 * sizeof(unsigned)));
     CHECK(hipMemset(d_busy, 0, wgs * 8 * sizeof(unsigned)));
     CHECK(hipFuncSetAttribute((const void *)probe<MODE, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));   // one workgroup per CU
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL((probe<MODE, BIG>), dim3(wgs), dim3(512), 96 * 1024, 0, blk, d_cyc, d_busy, 1.0f, sync, pub);
+        hipLaunchKernelGGL((probe<MODE, BIG>), dim3(wgs), dim3(512), 96 * 1024, 0, blk, d_cyc, d_busy, seed, sync, pub);
         CHECK(hipDeviceSynchronize());
     }
     std::vector<unsigned> cyc(wgs * 4), busy(wgs * 8);
@@ -179,6 +182,7 @@ int main(int argc, char **argv) {
         run<1, true>("other wave: MFMA 4x4x1, accumulators in VGPRs", 24, blk, d_cyc, d_busy, wgs, sync, 0);
         run<3, true>("other wave: v_fma_f32 chains", 96, blk, d_cyc, d_busy, wgs, sync, 0);
         run<6, true>("other wave: as an S wave (96 A regs, B from LDS)", 192, blk, d_cyc, d_busy, wgs, sync, 0);
+        run<6, true>("other wave: as an S wave, operands with random mantissas", 192, blk, d_cyc, d_busy, wgs, sync, 0, 0.5f);
     }
     return 0;
 }
