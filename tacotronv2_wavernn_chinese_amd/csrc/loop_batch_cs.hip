@@ -58,6 +58,10 @@
 #ifndef CS_PROF_ROUNDS
 #define CS_PROF_ROUNDS 0  // with CS_PROF_SPLIT: marker 8 of the C wave = 1000 x the data looks per step of ONE exchange (17 = x2, 7 = x3, 12 = f1, 16 = f2)
 #endif
+#ifndef CS_MINCHK
+#define CS_MINCHK 0   // developer knob: the data look's tags are checked with ONE wait and a v_min3 chain (~10 instructions) instead of a wait, two compares and two
+                      // scalar ANDs per load (~45): an instruction of this wave costs 25-35 cycles while the other wave of the SIMD issues MFMAs (tools/probe_mfma_vs_loads.hip)
+#endif
 #ifndef CS_PROF_FINE
 #define CS_PROF_FINE 0
 #endif
@@ -187,8 +191,18 @@ __device__ __forceinline__ void gather_rot(__amdgpu_buffer_rsrc_t rs, unsigned v
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
+#if CS_MINCHK
+        {   // a tag is never AHEAD of the step (nobody can publish step e + 2 into this parity while somebody still looks for e): all fresh <=> min == tag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned mn = 0xffffffffu;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) { const unsigned a = mn < g[0][m].y ? mn : g[0][m].y; mn = a < g[0][m].w ? a : g[0][m].w; }
+            ok = mn == tag;
+        }
+#else
 #pragma unroll
         for (int m = 0; m < NM; ++m) ok = ok && g[0][m].y == tag && g[0][m].w == tag;
+#endif
         if (rounds) *rounds += 1000u;   // instrumented build: data looks of this exchange, x 1000
         if (fine) fine[1] = (unsigned)__builtin_readcyclecounter();   // ... and when all of them are back and checked
         if (__all(ok) || dead) break;
@@ -246,7 +260,7 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
 #endif
     if (sent_cyc) *sent_cyc = (unsigned)__builtin_readcyclecounter();   // instrumented build: the sentinel wait ends here, the data look starts
     if (seen && (threadIdx.x & 63) == 0) *seen = (int)tag;   // "the data is there, my full look goes out now" (CS_LATE_H1 2: the S wave's look follows)
-#if CS_ROT || CS_DIAG >= 4 || CS_PROF_ROUNDS || CS_PROF_FINE
+#if CS_ROT || CS_DIAG >= 4 || CS_PROF_ROUNDS || CS_PROF_FINE || CS_MINCHK
     gather_rot<NM>(rs, voff, soff, tag, g, rot, dead, err, code, rounds, fine);
 #else
     const unsigned offs[1] = {soff};
@@ -923,7 +937,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     // to itself.  The four S waves then meet through LDS flags (s_barrier would need the C waves).
                     u4v gx[1][NM];
                     const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
-                    if (CS_ROT || CS_DIAG >= 4) gather_rot<NM>(mrs, gvoff, offs[0], epoch, gx, rot, dead, a.err, 22u);
+                    if (CS_ROT || CS_DIAG >= 4 || CS_MINCHK) gather_rot<NM>(mrs, gvoff, offs[0], epoch, gx, rot, dead, a.err, 22u);
                     else gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
                     PBW(1);
 #pragma unroll

@@ -6,7 +6,9 @@
 //   0 idle (s_sleep)   1 MFMA, accumulators in architectural VGPRs   2 MFMA, accumulators in AGPRs   3 v_fma_f32 chains (no MFMA)
 //   6 the MFMA loop of an S wave of loop_batch_cs.hip (96 resident A registers, 6 accumulator chains in VGPRs, two 16-byte LDS reads per 24 MFMAs)
 //   4 MFMA (VGPR form) with an s_nop 7 between the instructions (~half the issue density)      5 MFMA (AGPR form) + the B operand read from LDS every 4 MFMAs
-// Prints, per mode, the mean cycles of a look and the busy waves' instruction rate.
+// The looking waves check what they fetched in one of these ways (LCHK): 0 a few VALU behind one wait   1 C++ `ok = ok && tag == ...` per load (hipcc makes a
+// branchy sequence of it here: 2 240 cycles even beside an idle wave -- not what the kernel's ISA looks like)   2 a v_min3 chain   3 no loads: 64 dependent v_add_u32
+// Prints, per mode, the mean cycles of a look and the busy waves' instruction rate.  `./probe 256 all` prints the sibling-mode table of round 4.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +22,7 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int LOOKS = 200;     // looks per loader wave
 constexpr int NLOAD = 8;       // 16-byte loads per lane per look (R = 8)
 
-template <int MODE, bool BIG = false>
+template <int MODE, bool BIG = false, int LCHK = 0>
 __global__ __launch_bounds__(512) void probe(unsigned *blk, unsigned *out_cyc, unsigned *out_busy, float seed, int sync, int pub) {
     __shared__ int done;   // loader waves that have finished
     __shared__ f4 ldsb[64 * 8];
@@ -57,12 +59,33 @@ __global__ __launch_bounds__(512) void probe(unsigned *blk, unsigned *out_cyc, u
             __builtin_amdgcn_sched_barrier(0);
             const unsigned t0 = (unsigned)__builtin_readcyclecounter();
             __builtin_amdgcn_sched_barrier(0);
+            const unsigned tag0 = 0x01010101u;
             u4v g[NLOAD];
 #pragma unroll
-            for (int m = 0; m < NLOAD; ++m) g[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)m * 4096u, 16);
+            for (int m = 0; m < NLOAD; ++m) g[m] = LCHK == 3 ? (u4v){tag0, tag0, tag0, tag0} : __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)m * 4096u, 16);
+            const unsigned tag = 0x01010101u;   // what hipMemset(blk, 1) left in every word
+            if (LCHK == 0) {          // one wait, a few VALU
 #pragma unroll
-            for (int m = 0; m < NLOAD; ++m) sink += g[m].x ^ g[m].w;
-            asm volatile("" :: "v"(sink));
+                for (int m = 0; m < NLOAD; ++m) sink += g[m].x ^ g[m].w;
+                asm volatile("" :: "v"(sink));
+            } else if (LCHK == 1) {   // the check of loop_batch_cs.hip: per load a wait, two compares, two scalar ANDs (~45 instructions)
+                bool ok = true;
+#pragma unroll
+                for (int m = 0; m < NLOAD; ++m) ok = ok && g[m].y == tag && g[m].w == tag;
+                if (!__all(ok)) sink += 1;
+            } else if (LCHK == 2) {   // one wait, a v_min3 tree over the 16 tag words, one compare (~10 instructions)
+                unsigned mn = 0xffffffffu;
+#pragma unroll
+                for (int m = 0; m < NLOAD; m += 2) {
+                    const unsigned a = g[m].y < g[m].w ? g[m].y : g[m].w, b = g[m + 1].y < g[m + 1].w ? g[m + 1].y : g[m + 1].w;
+                    const unsigned c = a < b ? a : b;
+                    mn = mn < c ? mn : c;
+                }
+                if (!__all(mn == tag)) sink += 1;
+            } else {                  // LCHK 3: no loads at all -- 64 independent VALU instructions: what does ONE instruction of this wave cost?
+#pragma unroll
+                for (int k = 0; k < 64; ++k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(sink) : "v"(lane));
+            }
             __builtin_amdgcn_sched_barrier(0);
             const unsigned t1 = (unsigned)__builtin_readcyclecounter();
             __builtin_amdgcn_sched_barrier(0);
@@ -136,13 +159,13 @@ __global__ __launch_bounds__(512) void probe(unsigned *blk, unsigned *out_cyc, u
     }
 }
 
-template <int MODE, bool BIG = false>
+template <int MODE, bool BIG = false, int LCHK = 0>
 static void run(const char *what, int per_iter, unsigned *blk, unsigned *d_cyc, unsigned *d_busy, int wgs, int sync, int pub, float seed = 1.0f) {
     CHECK(hipMemset(d_cyc, 0, wgs * 4 * sizeof(unsigned)));
     CHECK(hipMemset(d_busy, 0, wgs * 8 * sizeof(unsigned)));
-    CHECK(hipFuncSetAttribute((const void *)probe<MODE, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));   // one workgroup per CU
+    CHECK(hipFuncSetAttribute((const void *)probe<MODE, BIG, LCHK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));   // one workgroup per CU
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL((probe<MODE, BIG>), dim3(wgs), dim3(512), 96 * 1024, 0, blk, d_cyc, d_busy, seed, sync, pub);
+        hipLaunchKernelGGL((probe<MODE, BIG, LCHK>), dim3(wgs), dim3(512), 96 * 1024, 0, blk, d_cyc, d_busy, seed, sync, pub);
         CHECK(hipDeviceSynchronize());
     }
     std::vector<unsigned> cyc(wgs * 4), busy(wgs * 8);
@@ -151,7 +174,7 @@ static void run(const char *what, int per_iter, unsigned *blk, unsigned *d_cyc, 
     double m = 0, mx = 0, rate = 0;
     for (unsigned c : cyc) { m += c; if (c > mx) mx = c; }
     for (int i = 0; i < wgs * 4; ++i) rate += busy[2 * i + 1] ? (double)busy[2 * i] * per_iter / busy[2 * i + 1] : 0.0;
-    printf("%s sync %d pub %d mode %d %-52s look: mean %7.0f max %7.0f cycles;  busy wave: %.3f instr/cycle\n", BIG ? "256 VGPRs" : "few VGPRs", sync, pub, MODE, what, m / cyc.size(), mx, rate / (wgs * 4));
+    printf("check %d %s sync %d pub %d mode %d %-52s look: mean %7.0f max %7.0f cycles;  busy wave: %.3f instr/cycle\n", LCHK, BIG ? "256 VGPRs" : "few VGPRs", sync, pub, MODE, what, m / cyc.size(), mx, rate / (wgs * 4));
 }
 
 int main(int argc, char **argv) {
@@ -172,17 +195,31 @@ int main(int argc, char **argv) {
         printf("   (CU %u)\n", (hw[0] >> 8) & 15u);
     }
     printf("%d workgroups x 512 threads, %d looks of %d x 16 B per lane (32 KB per workgroup and look)\n", wgs, LOOKS, NLOAD);
-    for (int sync = 0; sync < 2; ++sync) {
-        run<0>("other wave idle", 0, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<1>("other wave: MFMA 4x4x1, accumulators in VGPRs", 24, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<2>("other wave: MFMA 4x4x1, accumulators in AGPRs", 24, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<3>("other wave: v_fma_f32 chains", 96, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<6>("other wave: as an S wave (96 A regs, B from LDS)", 192, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<0, true>("other wave idle", 0, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<1, true>("other wave: MFMA 4x4x1, accumulators in VGPRs", 24, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<3, true>("other wave: v_fma_f32 chains", 96, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<6, true>("other wave: as an S wave (96 A regs, B from LDS)", 192, blk, d_cyc, d_busy, wgs, sync, 0);
-        run<6, true>("other wave: as an S wave, operands with random mantissas", 192, blk, d_cyc, d_busy, wgs, sync, 0, 0.5f);
+    // argv[2] = "all": the round-4 table (sibling modes x register allocation); default: how the look's CHECK code fares under the neighbour's MFMAs
+    if (argc > 2) {
+        for (int sync = 0; sync < 2; ++sync) {
+            run<0>("other wave idle", 0, blk, d_cyc, d_busy, wgs, sync, 0);
+            run<1>("other wave: MFMA 4x4x1, accumulators in VGPRs", 24, blk, d_cyc, d_busy, wgs, sync, 0);
+            run<2>("other wave: MFMA 4x4x1, accumulators in AGPRs", 24, blk, d_cyc, d_busy, wgs, sync, 0);
+            run<3>("other wave: v_fma_f32 chains", 96, blk, d_cyc, d_busy, wgs, sync, 0);
+            run<6>("other wave: as an S wave (96 A regs, B from LDS)", 192, blk, d_cyc, d_busy, wgs, sync, 0);
+            run<6, true>("other wave: as an S wave (96 A regs, B from LDS)", 192, blk, d_cyc, d_busy, wgs, sync, 0);
+            run<6, true>("other wave: as an S wave, operands with random mantissas", 192, blk, d_cyc, d_busy, wgs, sync, 0, 0.5f);
+        }
+        return 0;
     }
+    run<0, true, 0>("idle", 0, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<1, true, 0>("MFMA", 24, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<6, true, 0>("S-wave loop", 192, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<0, true, 1>("idle", 0, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<1, true, 1>("MFMA", 24, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<6, true, 1>("S-wave loop", 192, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<0, true, 2>("idle", 0, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<1, true, 2>("MFMA", 24, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<6, true, 2>("S-wave loop", 192, blk, d_cyc, d_busy, wgs, 1, 0);
+    run<0, true, 3>("idle", 0, blk, d_cyc, d_busy, wgs, 0, 0);
+    run<1, true, 3>("MFMA", 24, blk, d_cyc, d_busy, wgs, 0, 0);
+    run<3, true, 3>("v_fma", 96, blk, d_cyc, d_busy, wgs, 0, 0);
+    run<6, true, 3>("S-wave loop", 192, blk, d_cyc, d_busy, wgs, 0, 0);
     return 0;
 }
