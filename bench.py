@@ -33,14 +33,15 @@ Extra objects on the JSON line:
                    batch size: HBM for B=1 and MOL B=32 (`peak` = the 8 TB/s of the data sheet, `peak_measured` = a
                    read-only stream over 1 GiB timed in this run, `peak_measured_copy` = a device-to-device copy, read + write
                    bytes), the fp32 matrix/vector peak 157.3 TFLOP/s
-                   for B=64.  `traffic` = measured HBM bytes per launch from the PMC passes under profiles/ (a static
-                   number from that profile, not from this run: `traffic_source` says which file).  For B=1 the weights are
+                   for B=64.  `frac_of_f32_peak` = the same rate against the fp32 pipe for every config; `traffic` = measured HBM bytes per launch and
+                   `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1 024 SIMDs) from the PMC passes under profiles/
+                   (static numbers of that profile session: `traffic_source` names file + commit; null when the kernel sources changed since).  For B=1 the weights are
                    register/LDS resident and HBM is idle: the bound that actually binds is the exchange latency,
                    `latency_model` = {exchanges per step, all-gather round time of the 32 workgroups of one XCD measured by
                    bench_micro/handoff, floor_us} and `frac_of_latency_floor` = floor / measured us per step.
   cpu_baseline  -- the reference's generate() loop issued op for op on PyTorch-CPU on THIS box's host cores (oracle/torch_cpu_loop.py,
-                   kind "reference-ops (torch CPU, this box)": all cores + one thread, a bounded sample of BASELINE configs[0]'s clip),
-                   rank 0 at N=1 only;  cpu_port -- the C restatement (oracle/wavernn_oracle.c, OpenMP + AVX2) on the same clip;
+                   kind "reference-ops (torch CPU, this box)": ALL 55 000 steps of BASELINE configs[0]'s clip at <= 16 threads, samples at torch's
+                   untuned default thread count and at one thread), rank 0 at N=1 only;  cpu_port -- the C restatement (oracle/wavernn_oracle.c, OpenMP + AVX2) on the same clip;
   cpu_reference -- the UNMODIFIED reference generate() (PyTorch CPU) timed by oracle/time_reference.py where
                    /root/reference exists (the build container; `where` says so) -- the GPU box has no reference tree.
 """
@@ -73,46 +74,80 @@ CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
            2: dict(mode='RAW', bits=10, batch=64, name='configs[2]'),
            4: dict(mode='MOL', bits=9, batch=32, name='configs[4]'),
            3: dict(mode='RAW', bits=10, batch=64, name='configs[3]')}
-# HBM bytes of the loop kernel per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
-# correction of MI355X_MICROARCH.md + WRITE_SIZE), keyed by (config, kernel); absent = not measured.  STATIC numbers.
-TRAFFIC_SOURCE = ('profiles/r04_rocprofv3_summary.txt (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh taken on the tree at commit 782b7ac, '
-                  'the shipped loop kernels -- not this run)')
-TRAFFIC_BYTES_PER_LAUNCH = {(1, 3): 79_390_821 + 1_979_317,              # fetch_c1 + write_c1, per segment launch (loop_team2_kernel)
-                            (2, 5): 1_798_203_904 + 421_802_272,          # fetch_c2 + write_c2: the one launch of 64 x 110 275 samples (loop_batch_cs_kernel<RAW, 2>)
-                            (3, 5): 1_798_203_904 + 421_802_272,
-                            (4, 5): 1_116_693_888 + 29_551_872}           # fetch_c4 + write_c4: 32 x 110 275 samples (loop_batch_cs_kernel<MOL, 1>)
+# Counter numbers of the loop kernels (HBM bytes and MFMA-busy cycles per launch) come from the rocprofv3 --pmc passes of tools/profile_round.sh,
+# kept as profiles/<round>_pmc.json by tools/pmc_summary.py --json: STATIC numbers of that profile session, not of this run.  The file records the
+# commit it was taken at and a hash of the kernel sources (csrc/*.hip, *.h, include/wavernn_amd.h); when the tree's sources hash differently -- a
+# kernel was edited after the last profile -- the counter fields are reported as null instead of silently describing another kernel.
+PMC_FILE = os.path.join('profiles', 'r05_pmc.json')
+ENGINE_HZ, N_SIMD = 2.4e9, 1024      # MI355X_MICROARCH.md: 2.4 GHz peak engine clock, 256 CUs x 4 SIMDs
+
+
+def csrc_sha() -> str:
+    """sha256 over the kernel sources in the tree (names + contents, sorted): what the counter file must have been taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'tacotronv2_wavernn_chinese_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')) + [os.path.join(ROOT, 'include', 'wavernn_amd.h')]):
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc() -> dict:
+    """{'ok': bool, 'why': str, 'source': str, 'configs': {cfg_id: {...}}} -- ok only if the file exists and was taken on these sources."""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return dict(ok=False, why=f'{PMC_FILE} not present', source=None, configs={})
+    src = (f'{PMC_FILE} (static: rocprofv3 --pmc passes of tools/profile_round.sh taken at commit {rec.get("commit")}, kernel sources sha256 {rec.get("csrc_sha")}'
+           ' -- not this run)')
+    now = csrc_sha()
+    if rec.get('csrc_sha') != now:
+        return dict(ok=False, why=f'{PMC_FILE} was taken on kernel sources {rec.get("csrc_sha")} (commit {rec.get("commit")}), the tree has {now}: counters withheld',
+                    source=src, configs={})
+    return dict(ok=True, why='', source=src, configs={int(k): v for k, v in rec.get('configs', {}).items()})
+
+
 # What bounds the B=1 latency kernel (DESIGN.md 3.2): 4 dependent all-gathers among the 32 workgroups of one XCD per step.
 # bench_micro/handoff.hip measures one such round (512 granules published, polled with sc1 loads, written to LDS, 2
 # barriers, NO compute between rounds): profiles/r03_handoff_microbench.txt.
+DM_EXCHANGES = 6   # all-gather rounds per sample of dm_team_kernel (DESIGN.md 3.4)
 LATENCY_MODEL = dict(exchanges_per_step=4, barriers_per_step=5, allgather_round_us=0.746, raw_hop_us=0.27,
                      source='profiles/r03_handoff_microbench.txt (gather st=plain ld=sc1 team=32: 0.746-0.768 us per round; '
                             'raw one-way hop profiles/r01_handoff_microbench.txt)')
 
 
-def cpu_reference_ops(frames: int = 200, steps: int = 3000) -> dict:
+def cpu_reference_ops(frames: int = 200) -> dict:
     """The reference's generate() loop issued op for op on PyTorch-CPU ON THIS BOX (oracle/torch_cpu_loop.py: nn.GRUCell /
     nn.Linear / softmax / Categorical.sample() as fatchord_version.py:194-237; pinned to the reference's own labels by
-    tests/test_oracle_golden.py), on BASELINE configs[0]'s clip, a bounded sample of its 55 000 steps, all cores and one thread."""
+    tests/test_oracle_golden.py) on BASELINE configs[0]'s clip: ALL of its 55 000 loop steps (wavernn_gen.py:126 runs the whole clip) at the
+    thread count that suits this box (<= 16), plus bounded samples at torch's untuned default (one thread per core) and at one thread."""
     from oracle import torch_cpu_loop as tl
     from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
     sd = make_state_dict(0, variant='peaky')
     mels = make_mels(1234, 1, frames)
     ncpu = os.cpu_count() or 1
-    # torch's default is one thread per core; on a many-core host that is the WORST setting for 512-wide matrix-vector products (every op
-    # is an OpenMP barrier), so the leg also runs at <= 16 threads and reports the best of the two as `value` -- with both kept
-    threads = sorted({ncpu, min(ncpu, 16)}, reverse=True)
-    tl.run(sd, mels, 32, threads[-1], max_seconds=5.0)   # first-call overheads (thread pool, MKL plans)
-    runs = [tl.run(sd, mels, steps, th, max_seconds=8.0) for th in threads]
-    one = tl.run(sd, mels, max(200, steps // 3), 1, max_seconds=6.0)
-    rate = lambda r: r['steps'] / max(r['loop_seconds'], 1e-9) / 1000.0
-    allc = max(runs, key=rate)
-    by_threads = {str(r['threads']): round(rate(r), 4) for r in runs}
-    return dict(value=round(rate(allc), 4), unit='ksamples/s', cores=allc['threads'], host_cores=ncpu, by_threads=by_threads,
-                kind='reference-ops (torch CPU, this box)',
-                one_thread=round(one['steps'] / one['loop_seconds'] / 1000.0, 4),
-                sample=f'BASELINE configs[0] clip (mel 80x{frames}, RAW 10-bit, B=1): the first {allc["steps"]} of its {frames * HOP} loop steps with the '
-                       f'reference\'s own op sequence on torch-CPU ({allc["loop_seconds"]:.1f} s on {allc["threads"]} threads of {ncpu} cores; {one["steps"]} steps in '
-                       f'{one["loop_seconds"]:.1f} s on 1 thread); oracle/torch_cpu_loop.py, reproduces the reference\'s labels bit for bit')
+    L = frames * HOP
+    tuned = min(ncpu, 16)
+    tl.run(sd, mels, 32, tuned, max_seconds=5.0)   # first-call overheads (thread pool, MKL plans)
+    full = tl.run(sd, mels, L, tuned, max_seconds=90.0)                  # the whole clip (~20 s on the GPU box's host)
+    # torch's default is one thread per core; on a many-core host that is the WORST setting for 512-wide matrix-vector products (every op is
+    # an OpenMP barrier): what `python wavernn_gen.py` does untuned on this box -- reported as it is, next to the tuned figure
+    dflt = tl.run(sd, mels, 3000, ncpu, max_seconds=8.0) if ncpu != tuned else full
+    one = tl.run(sd, mels, 3000, 1, max_seconds=6.0)
+    rate = lambda r: round(r['steps'] / max(r['loop_seconds'], 1e-9) / 1000.0, 4)
+    whole = full['steps'] == L
+    return dict(value=rate(full), unit='ksamples/s', cores=tuned, host_cores=ncpu,
+                by_threads={str(tuned): rate(full), str(ncpu): rate(dflt), '1': rate(one)},
+                untuned_default_threads=dict(threads=ncpu, value=rate(dflt), steps=dflt['steps']),
+                kind='reference-ops (torch CPU, this box)', one_thread=rate(one),
+                sample=(f'ALL {L} loop steps' if whole else f'the first {full["steps"]} of the {L} loop steps (90 s cap)') +
+                       f' of BASELINE configs[0] (mel 80x{frames}, RAW 10-bit, B=1) with the reference\'s own op sequence on torch-CPU: {full["loop_seconds"]:.1f} s on {tuned} '
+                       f'threads of {ncpu} cores; torch\'s default of {ncpu} threads: {dflt["steps"]} steps in {dflt["loop_seconds"]:.1f} s; 1 thread: {one["steps"]} steps in '
+                       f'{one["loop_seconds"]:.1f} s; oracle/torch_cpu_loop.py, reproduces the reference\'s labels bit for bit')
 
 
 def cpu_baseline(frames: int = 200, max_threads: int = 16) -> dict:
@@ -277,6 +312,34 @@ def fold_auto_leg(dev, frames: int = T_FRAMES, reps: int = 3) -> dict:
     return out
 
 
+def dm_leg(dev, n: int = 50_000) -> dict:
+    """The secondary dual-softmax model (deepmind_version.py:75-165) on the driver-visible line: wrnn_dm_generate,
+    hidden 896, `n` samples on the team kernel (one XCD), wall time of the call (launch + loop + sync)."""
+    import torch
+    from tacotronv2_wavernn_chinese_amd.deepmind import WaveRNN as DM
+    from tacotronv2_wavernn_chinese_amd.synth import make_dm_state_dict
+    m = DM()
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in make_dm_state_dict(0).items()})
+    m.to(dev)
+    m.generate(2000, seed=1, kernel=2)
+    t0 = time.perf_counter()
+    out, c, f = m.generate(n, seed=2, kernel=2)
+    dt = time.perf_counter() - t0
+    us = dt / n * 1e6
+    ex = DM_EXCHANGES
+    floor = ex * LATENCY_MODEL['allgather_round_us']
+    res = {'metric': 'secondary dual-softmax WaveRNN (16-bit, coarse/fine), audio ksamples/sec, batch=1', 'value': round(n / dt / 1000.0, 1), 'unit': 'ksamples/s',
+           'steps': 1, 'warmup': 1, 'ms_per_step': round(dt * 1e3, 3), 'dtype': 'f32',
+           'config': {'workload': f'deepmind_version.WaveRNN(hidden 896, quantisation 256).generate({n}), seeded synthetic weights, Philox noise, team kernel (32 CUs of one XCD)',
+                      'us_per_sample': round(us, 4), 'distinct_coarse': int(len(np.unique(c))), 'distinct_fine': int(len(np.unique(f)))},
+           'roofline': {'bound': 'latency', 'latency_model': {'exchanges_per_sample': ex, 'allgather_round_us': LATENCY_MODEL['allgather_round_us'], 'floor_us': round(floor, 3),
+                                                             'source': LATENCY_MODEL['source']},
+                        'frac_of_latency_floor': round(floor / us, 4)}}
+    del m
+    torch.cuda.empty_cache()
+    return res
+
+
 def _kernel_name(k: int) -> str:
     from tacotronv2_wavernn_chinese_amd import _cabi
     return _cabi.KERNEL_NAMES.get(k, str(k))
@@ -419,8 +482,17 @@ def run_config(cfg_id: int, *, world: int, rank: int, dev, dry: bool, steps: int
                      f'x steps per launch / average loop-kernel launch duration (HIP events around the {launches} launch(es) of one call); '
                      'peak = data-sheet HBM bandwidth, peak_measured = read-only stream / peak_measured_copy = device copy (read + write) timed in this run.  NOTIONAL for '
                      'this kernel: the weights are register/LDS resident and never leave the chip (traffic: measured HBM bytes per launch)')
-    roof['traffic'] = TRAFFIC_BYTES_PER_LAUNCH.get((cfg_id, kernel_ran)) if T == T_FRAMES else None
-    roof['traffic_source'] = TRAFFIC_SOURCE if roof['traffic'] is not None else None
+    # the physically relevant ceilings next to the SURVEY-binding one: the fp32 matrix / vector pipe for every config ...
+    roof['frac_of_f32_peak'] = round(rate * FLOP_PER_SAMPLE[mode] / F32_PEAK, 4)
+    # ... and what the counters of the last profile session say (static, withheld when the kernel sources changed since: load_pmc)
+    pmc = load_pmc()
+    pc = pmc['configs'].get(2 if cfg_id == 3 else cfg_id) if (pmc['ok'] and T == T_FRAMES and B == cfg['batch']) else None
+    if pc is not None and _kernel_name(kernel_ran) not in pc.get('kernel', ''):
+        pc = None
+    roof['traffic'] = (pc['fetch_bytes_per_launch'] + pc['write_bytes_per_launch']) if pc else None
+    # matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES of one launch / (this run's launch duration x 2.4 GHz x 1 024 SIMDs)
+    roof['mfma_busy_frac'] = round(pc['mfma_busy_cycles_per_launch'] / ((k_ms / launches) * 1e-3 * ENGINE_HZ * N_SIMD), 4) if pc else None
+    roof['traffic_source'] = pmc['source'] if pc else (pmc['why'] or None)
     if kernel_ran == _cabi.KERNEL_TEAM2 and rows <= 8:
         lm = dict(LATENCY_MODEL)
         lm['floor_us'] = round(lm['exchanges_per_step'] * lm['allgather_round_us'], 3)
@@ -530,12 +602,16 @@ def main() -> int:
         # and on 2 / 8 gloo ranks (CPU) -- never on 8 real GPUs -- so a watchdog stands behind it: if the leg is not back within
         # SCALE_LEG_TIMEOUT seconds, rank 0 prints the headline line with the leg marked as timed out and every rank leaves.
         import threading
+        printed = threading.Lock()   # the line is printed once: by the watchdog or by the main thread, whoever takes this first (never released)
 
         def give_up():
+            if not printed.acquire(blocking=False):
+                return                # the main thread is already printing: the leg came back right at the limit
             if rank == 0 and out is not None:
                 out['extra_configs'] = {'3': {'error': f'configs[3] leg did not return within {SCALE_LEG_TIMEOUT} s (watchdog); headline unaffected'}}
+                out['scale_leg_timed_out'] = True
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(0 if rank == 0 else 75)   # rank 0 has delivered the headline; the other ranks leave with EX_TEMPFAIL so that the launcher's log shows the hang
         dog = threading.Timer(SCALE_LEG_TIMEOUT, give_up)
         dog.daemon = True
         dog.start()
@@ -545,6 +621,9 @@ def main() -> int:
         except Exception as ex:   # every rank raises or none does (the collectives are symmetric); never sink the headline
             scale_extra = {'error': repr(ex)}
         dog.cancel()
+        if not printed.acquire(blocking=False):   # the watchdog fired while the leg was returning: it prints and exits for us
+            time.sleep(30)
+            return 0
     if rank == 0 and out is not None:
         if scale_extra is not None:
             keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'roofline', 'config', 'data', 'dry_run_check', 'error')
@@ -567,6 +646,11 @@ def main() -> int:
                 extra['fold_auto'] = fold_auto_leg(dev)
             except Exception as ex:
                 extra['fold_auto'] = {'error': repr(ex)}
+            note('extra leg dm')
+            try:
+                extra['dm'] = dm_leg(dev)
+            except Exception as ex:
+                extra['dm'] = {'error': repr(ex)}
             note('extra leg train_step')
             try:
                 extra['train_step'] = train_step_leg(dev)

@@ -147,3 +147,21 @@ def training_step(state_dict: Dict[str, np.ndarray], mode: str, x: np.ndarray, m
     grads = {k: v.grad.detach().cpu().numpy() for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
     return dict(loss=float(loss.detach()), logits=y_hat.detach().cpu().numpy(), grads=grads, d_mels_up=mels_up.grad.detach().cpu().numpy(),
                 d_aux=aux.grad.detach().cpu().numpy(), mels_up=mels_up.detach().cpu().numpy(), aux=aux.detach().cpu().numpy())
+
+
+def float64_logits_at(state_dict: Dict[str, np.ndarray], mel: np.ndarray, x_fed: np.ndarray, steps, pad: int = 2, device='cuda') -> np.ndarray:
+    """fc3 outputs in FLOAT64 at `steps` of ONE row whose loop was fed the values `x_fed` (L,): generate()'s arithmetic (:183-223: zero-padded
+    mel, eval-mode upsample network, x_0 = 0 :197, then the value appended to `output` :227,:236) with every operation in double precision.
+    Used by the parity tests to say which side a near-tie of the sampler's race falls on in exact arithmetic.  mel (n_mels, T) float32."""
+    steps = [int(t) for t in steps]
+    n = max(steps) + 1
+    with torch.no_grad():
+        sd = {k: torch.as_tensor(np.asarray(v)).to(device=device, dtype=torch.float64) for k, v in state_dict.items()
+              if np.asarray(v).dtype.kind == 'f'}
+        m = torch.as_tensor(np.asarray(mel)).to(device=device, dtype=torch.float64)[None]
+        m = F.pad(m, (pad, pad))                                                    # pad_tensor(side='both') :183, :281-291
+        mels_up, aux = upsample(sd, m, pad=pad, training=False)
+        x = torch.zeros(1, n, dtype=torch.float64, device=device)
+        x[0, 1:] = torch.as_tensor(np.asarray(x_fed[:n - 1])).to(device=device, dtype=torch.float64)
+        y = loop_forward(sd, x, mels_up[:, :n], aux[:, :n])
+        return y[0, steps].cpu().numpy()

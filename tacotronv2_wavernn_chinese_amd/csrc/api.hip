@@ -162,9 +162,12 @@ int wrnn_create(const wrnn_config *cfg, wrnn_handle **out) {
             hipError_t e = wrnn_batch_occupancy(cfg->mode, nq, false, &blocks, &lds);
             if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_batch_kernel cannot be resident (LDS/registers)"; }
         }
-        for (int nq = 1; nq <= wrnn_batch_cs_max_nq(cfg->mode) && h->team_ok; ++nq) {
+        // its own flag (round-4 advisor): a toolchain that allocates this kernel's registers differently must not take TEAM2 and BATCH down with
+        // it -- AUTO then runs the one-wave-per-SIMD batch kernel, only an explicit WRNN_KERNEL_BATCH_CS is an error
+        h->cs_ok = h->team_ok;
+        for (int nq = 1; nq <= wrnn_batch_cs_max_nq(cfg->mode) && h->cs_ok; ++nq) {
             hipError_t e = wrnn_batch_cs_occupancy(cfg->mode, nq, false, &blocks, &lds);
-            if (e != hipSuccess || blocks < 1) { h->team_ok = false; h->team_why = "loop_batch_cs_kernel cannot be resident (LDS/registers)"; }
+            if (e != hipSuccess || blocks < 1) h->cs_ok = false;
         }
         (void)hipGetLastError();
     }
@@ -548,8 +551,9 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
         if (team_no) kernel = WRNN_KERNEL_SIMPLE;
         // one row per XCD team: the latency kernel; more rows: the batch step with critical / shadow wave roles (round 4: 7.5 against 6.85
         // Msamples/s at RAW B = 64, 5.6 against 5.3 at MOL B = 32; WRNN_KERNEL_BATCH stays available by name)
-        else kernel = rows <= h->n_teams ? WRNN_KERNEL_TEAM2 : WRNN_KERNEL_BATCH_CS;
+        else kernel = rows <= h->n_teams ? WRNN_KERNEL_TEAM2 : (h->cs_ok ? WRNN_KERNEL_BATCH_CS : WRNN_KERNEL_BATCH);
     }
+    if (kernel == WRNN_KERNEL_BATCH_CS && !team_no && !h->cs_ok) team_no = "loop_batch_cs_kernel cannot be resident (LDS/registers); WRNN_KERNEL_BATCH can";
     if (kernel == WRNN_KERNEL_SIMPLE) {
         HIP_TRY(h, wrnn_launch_loop_simple(a, s));
     } else if (kernel == WRNN_KERNEL_TEAM2 || kernel == WRNN_KERNEL_BATCH || kernel == WRNN_KERNEL_BATCH_CS) {
@@ -600,7 +604,8 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             // team kernels of one device run one after the other, whatever handle / stream launches them (wavernn_amd.h); the
             // mailbox reset belongs inside the gate: the handle's previous team kernel may still be reading it
             HIP_TRY(h, wrnn_team_gate_enter(h->cfg.device, s));
-            hipError_t le = hipMemsetAsync(h->mail, 0, mail_bytes, s);
+            // (BATCH_CS publishes untagged words: an empty mailbox word is 0xffffffff there, see loop_batch_cs.hip; BATCH: tag 0 = no step)
+            hipError_t le = hipMemsetAsync(h->mail, cs ? 0xff : 0, mail_bytes, s);
             if (le == hipSuccess) le = hipMemsetAsync(h->ctl, 0, 128, s);
             if (le == hipSuccess) le = cs ? wrnn_launch_loop_batch_cs(ba, s) : wrnn_launch_loop_batch(ba, s);
             const hipError_t ge = wrnn_team_gate_leave(h->cfg.device, s);

@@ -7,115 +7,112 @@
 // wave cannot saturate the matrix pipe anyway (8.1 cycles per 4x4x1 MFMA per wave, 4.07 per SIMD with two waves).  Here a SIMD
 // holds two waves of 256 registers with different jobs, as in loop_team2.hip:
 //   waves 0-3 "C" (critical): W_ih2 (96) + fc1 (32) + fc2 (32) weights in VGPRs, the fc3 slice in LDS: phase A (I + GRU1),
-//                             phase B (GRU2), fc1, fc2, fc3 + the race; the four gathers of the serial chain (x2, x3, fc1, fc2)
-//                             and the winners.  Nothing else: between a publish and its gather a C wave only polls.
-//   waves 4-7 "S" (shadow):   W_hh1 (96) + W_hh2 gates r,z (64) in VGPRs, gate n in LDS: the h1' gather (off the serial chain
-//                             now: C waits for x2 only), gh1' = W_hh1.h1', gh2' = W_hh2.(x3 - x2), the sampling noise and the
-//                             conditioning of the NEXT step.  Results go to the C wave of the same SIMD -- same lane = same
-//                             (unit, batch row) -- through small LDS slots, separated by the step's 5 workgroup barriers.
+//                             phase B (GRU2), fc1, fc2, half of fc3 + the race; the four gathers of the serial chain and the winners.
+//   waves 4-7 "S" (shadow):   W_hh1 (96) + W_hh2 gates r,z (64) in VGPRs: gh1' = W_hh1.h1', gh2' = W_hh2.(x3 - x2), the sampling
+//                             noise, the conditioning of the NEXT step, the other half of fc3.  Results go to the C wave of the same
+//                             SIMD -- same lane = same (unit, batch row) -- through small LDS slots, separated by the step's 5
+//                             workgroup barriers.  An S wave never looks at the mailbox (round 5).
 // No AGPR parking: hipcc splits a 256-register wave 128 : 128 between VGPRs and AGPRs as soon as a kernel touches an AGPR, so this
 // file is compiled with -mllvm -amdgpu-mfma-vgpr-form (MFMA results in VGPRs; see the Makefile) and all 160 weights are plain floats.
 //
-// Team, residency, mailbox regions, granule protocol, thread <-> (unit, row) map, B-operand order in LDS, the K-phase fold and
-// the software-pipelined MFMA loops are those of loop_batch.hip (batch_common.h).  Per step: 5 exchanges, 5 barriers (all 8 waves).
-//   window 1: C phase A, publish x2 | h1', gather x2 -> P          S gather h1' -> H1
-//   window 2: C phase B (W_ih2.x2), publish x3, gather -> Q         S W_hh1.h1' -> gh1 slots
-//   window 3: C fc1, publish, gather -> H1                          S W_hh2.(Q - P) -> gh2 slots
-//   window 4: C fc2, publish, gather -> P                           S noise of step t+1 -> nz slots (other parity)
-//   window 5: C fc3 + race, publish, candidates, winners -> xn      S conditioning of step t+1 -> cd / frame-constant slots
+// Team, residency, thread <-> (unit, row) map, B-operand order in LDS, the K-phase fold and the software-pipelined MFMA loops are those
+// of loop_batch.hip (batch_common.h).  Per step: 5 exchanges (RAW; MOL 4), 5 barriers (all 8 waves):
+//   window 1: C phase A, publish {x2, h1'}, gather -> P and H1                         S noise of this step -> nz slots
+//   window 2: C phase B (W_ih2.x2), publish x3, gather -> Q                            S W_hh1.h1' -> gh1 slots (starts AT B1, beside phase B)
+//   window 3: C fc1, publish, gate n of W_hh2.(Q - P) while the data travels, gather -> H1      S W_hh2 r,z.(Q - P) -> gh2 slots
+//   window 4: C fc2, publish, gather -> P                                              S conditioning of step t+1 -> cd slots
+//   window 5: C / S half of fc3 each (+ race, RAW), publish, candidates, winners -> xn         S frame constants; RAW 8 rows: the winner of row wl + 4
+//
+// THE EXCHANGE PROTOCOL (round 5; rounds 2-4 published 8-byte {tag = step, value} granules and the S waves gathered h1' themselves):
+//   * a published vector is R x 512 plain 4-byte WORDS in the order [rq][wl][S][iu][j][e] (every 2 KB holds words of all 32 producers;
+//     a 16-byte load returns the four e of one (rq, S, kp, j) = one ds_write_b128 in B-operand order).  An empty mailbox word holds
+//     CS_EMPTY = 0xffffffff -- a NaN bit pattern no fp32 operation of this kernel produces (the hardware's NaN is 0x7fc00000) -- so THE
+//     DATA IS THE FLAG without a tag: half the bytes of a look (the tags were half of every look: 32 KB per workgroup and exchange at
+//     8 rows through a 64 B/clk port; round-4 diagnostic: a look of half the bytes is worth +4.7 % / +2.2 %).
+//   * x2 and h1' of a (unit, row) travel as ONE 8-byte pair (one store): the C waves' x2 look brings h1' with it -- the bytes of the old
+//     {tag, x2} look -- and writes both P and H1.  The S waves' own 32 KB look (2 280 cycles at R = 8, stretched by the C waves' phase-B
+//     MFMAs), their LDS meeting point and its flags are gone; W_hh1.h1' starts at B1 and ends before the C waves' x3 look goes out
+//     (profiles/r04_batch_cs_experiments.txt: a look beside a multiplying neighbour wave returns only when the neighbour's MFMA stream ends).
+//   * who empties a word: its producer.  Step e uses parity p = e & 1.  When a workgroup has gathered the pairs of step e from all 32
+//     workgroups, every workgroup has finished every read of step e - 1 (a pair is published after the previous step's last gather), so
+//     the producer stores CS_EMPTY into its own words of parity 1 - p -- together with its x3 publish (one store round trip for both).
+//     They must have reached the L2 before anybody polls parity 1 - p again (step e + 1): the producer waits for its stores
+//     (s_waitcnt vmcnt(0), free by then) before it publishes fc1 of step e, and nobody enters step e + 1 without having gathered that.
+//     A pass (batch) boundary changes nothing: the epoch keeps counting, the first gather of the next batch empties the last step's words.
+//   * api.hip fills the mailbox with 0xff bytes before the launch.  A model that produces the CS_EMPTY pattern itself (only possible with
+//     such NaN payloads in its inputs) runs into the bounded spin and reports WRNN_ERR_TIMEOUT -- never a silently wrong sample.
+//   * the race candidates (RAW) keep {tag | class, score} granules: one per wave, row and step.
 #include "batch_common.h"
 
 #define CS_THREADS 512
-// developer knobs (tools/build_variant.sh): CS_PRIO 1 = the C waves run at s_setprio 3; CS_GATHER 0 = sentinel first, 1 = a full look at once,
-// 2 = s_sleep(CS_DELAY) and then a full look (both with the sentinel fall-back); CS_YIELD 1 = an S wave issues no MFMA while the C wave of its SIMD folds / evaluates gates (token in LDS), 2 = while that C wave's x3 / f1 data look is in flight
+// Developer knobs (tools/build_variant.sh NAME loop_batch_cs -DCS_...).  What round 4 measured and rejected -- slice rotation, a throttled shadow product,
+// every polling variant except "sentinel slice first, then everything", yielding shadow waves, a v_min3 tag check, the wrong-result timing diagnostics of
+// the shadow products' operands -- is recorded in profiles/r04_batch_cs_experiments.txt and no longer lives in this file.
 #ifndef CS_PRIO
-#define CS_PRIO 1
-#endif
-#ifndef CS_GATHER
-#define CS_GATHER 0
+#define CS_PRIO 1        // the C waves run at s_setprio 3: the two waves of a SIMD compete for issue slots, the serial chain goes first
 #endif
 #ifndef CS_SPLIT_WIN
-#define CS_SPLIT_WIN 1   // RAW, 8 rows per team: the winner of batch row wl + 4 is reduced by the S wave (window 5, behind its conditioning work)
-#endif
-#ifndef CS_SPRIO
-#define CS_SPRIO 1   // the S waves' h1' gather + meeting point run at the C waves' priority (+1 % at R = 4, nothing at R = 8)
-#endif
-#ifndef CS_NOISE_W1
-#define CS_NOISE_W1 1   // the sampler's noise of a step is prepared in window 1 of that step (0: in window 4 of the step before)
+#define CS_SPLIT_WIN 1   // RAW, 8 rows per team: the winner of batch row wl + 4 is reduced by the S wave (window 5)
 #endif
 #ifndef CS_FC3_SPLIT
-#define CS_FC3_SPLIT 1   // MOL: fc3 shared between the C and the S wave of a SIMD
+#define CS_FC3_SPLIT 1   // MOL: fc3 shared between the C and the S wave of a SIMD (each wave 4 of the SIMD's 8 rows)
 #endif
-#ifndef CS_COND_W4
-#define CS_COND_W4 (MODE == WRNN_MODE_MOL)   // MOL: the conditioning of the next step in window 4 (in window 5 the C waves waited for it at B4b: 780 cycles)
+#ifndef CS_FC3_SPLIT_RAW
+#define CS_FC3_SPLIT_RAW 0   // the same for RAW (round 5, session 1: the S waves' half ends later than the C waves', the candidates wait doubles: -2 %)
+#endif
+#ifndef CS_PAIR
+#define CS_PAIR 1        // 1: x2 and h1' travel as one 8-byte pair, the C waves' look writes P and H1, the S waves never look;  0: two word vectors, the S waves
+                         // gather h1' themselves behind B1 and meet through LDS flags (the round-4 schedule on the round-5 protocol)
 #endif
 #ifndef CS_LATE_FOLD
-#define CS_LATE_FOLD 1   // the fold of a shadow product runs behind the barrier that ends the product's window
+#define CS_LATE_FOLD (!CS_PAIR)   // the fold of a shadow product runs behind the barrier that ends its window (round 4: with their own h1' look in window 2 the S
+                                  // waves were the last at B2 / B3); with CS_PAIR they have ~3 000 cycles of slack there and fold at once
 #endif
-#ifndef CS_THROTTLE
-#define CS_THROTTLE 0
+#ifndef CS_SMPRIO
+#define CS_SMPRIO 0      // s_setprio of an S wave while it issues the MFMAs of a shadow product (0 = stays below the C wave's 3)
 #endif
-#ifndef CS_PROF_ROUNDS
-#define CS_PROF_ROUNDS 0  // with CS_PROF_SPLIT: marker 8 of the C wave = 1000 x the data looks per step of ONE exchange (17 = x2, 7 = x3, 12 = f1, 16 = f2)
+#ifndef CS_YIELD
+#define CS_YIELD 0       // an S wave issues MFMAs of a shadow product only while the C wave of its SIMD multiplies or waits for a sentinel (token in LDS, looked
+                         // at in front of every slab): 1 = not beside C's fold / gates / publish, 2 = not beside C's data look + LDS write either
 #endif
-#ifndef CS_MINCHK
-#define CS_MINCHK 0   // developer knob: the data look's tags are checked with ONE wait and a v_min3 chain (~10 instructions) instead of a wait, two compares and two
-                      // scalar ANDs per load (~45): an instruction of this wave costs 25-35 cycles while the other wave of the SIMD issues MFMAs (tools/probe_mfma_vs_loads.hip)
+#ifndef CS_WN_ON_C
+#define CS_WN_ON_C 1     // gate n of W_hh2.(x3 - x2) (A operands in LDS, 64 MFMAs at 8 rows) by the C wave between its fc1 publish and the fc1 look: the
+                         // data needs >= 600 cycles to arrive anyway, and the S waves' product (what the fc1 look waits for) shrinks by a third
 #endif
-#ifndef CS_PROF_FINE
-#define CS_PROF_FINE 0
+#ifndef CS_COND_W4_RAW
+#define CS_COND_W4_RAW 0
+#endif
+#ifndef CS_COND_W4
+#define CS_COND_W4 (MODE == WRNN_MODE_MOL || CS_COND_W4_RAW)   // the conditioning of the next step in window 4 (MOL: in window 5 the C waves waited for it at B4b)
 #endif
 #ifndef CS_PROF_SPLIT
-#define CS_PROF_SPLIT 0   // instrumented build: the C waves' exchanges are reported in two parts (sentinel wait: markers 17 / 7 / 12 / 16, the rest under the usual marker)
+#define CS_PROF_SPLIT 0  // instrumented build: the C waves' exchanges are reported in two parts (sentinel wait: markers 17 / 7 / 12 / 16, the rest under the usual marker)
 #endif
 #if CS_PROF_SPLIT
-#define GSF_DECL unsigned ts_ = 0, rnd_ = 0, fine_[2] = {0, 0}
-#define GSF_TS , PROF ? &ts_ : nullptr, PROF ? &rnd_ : nullptr, (PROF && CS_PROF_FINE) ? fine_ : nullptr
-// CS_PROF_FINE = marker of ONE exchange (7 = x3, 12 = f1, 16 = f2): only that exchange is split, and its data look in three parts -- marker 8: sentinel seen -> first
-// load back, marker 17: first -> all loads back and checked; the exchange's usual marker keeps the LDS write
-#define GSF_ACC(i)                                                                                              \
-    do {                                                                                                        \
-        if (PROF && CS_PROF_FINE == (i)) { PBS(i, ts_); PBS(8, fine_[0]); PBS(17, fine_[1]); }                  \
-        else if (!CS_PROF_FINE) PBS(i, ts_);                                                                    \
-        if (PROF && CS_PROF_ROUNDS == (i) && lane == 0 && wl == 0) prof_lds[8] += rnd_;                         \
-    } while (0)
+#define GSF_DECL unsigned ts_ = 0
+#define GSF_TS , PROF ? &ts_ : nullptr
+#define GSF_ACC(i) PBS(i, ts_)
 #else
 #define GSF_DECL
 #define GSF_TS
 #define GSF_ACC(i)
 #endif
 #ifndef CS_PROF_WG
-#define CS_PROF_WG 0   // instrumented build: the workgroup (arrival rank inside its team) whose wave 0 / wave 4 are reported
-#endif
-#ifndef CS_ROT
-#define CS_ROT 0
+#define CS_PROF_WG 0     // instrumented build: the workgroup (arrival rank inside its team) whose wave 0 / wave 4 are reported
 #endif
 #ifndef CS_DIAG
-#define CS_DIAG 0   // TIMING DIAGNOSTIC ONLY (wrong results): bit 0 = the S waves skip the W_hh1 MFMAs, bit 1 = the W_hh2 MFMAs; 4 / 8 and 16 / 32 / 64: see diag_skip, diag_gates
-#endif
-#ifndef CS_DGS
-#define CS_DGS 1   // slabs of B operands the S waves' W_hh1 loop requests ahead at 8 rows per team
+#define CS_DIAG 0        // TIMING DIAGNOSTIC ONLY (wrong results): bit 0 = the S waves skip the W_hh1 MFMAs, bit 1 = the W_hh2 MFMAs
 #endif
 #ifndef CS_EARLY_LOOK
-#define CS_EARLY_LOOK 8   // the full look goes out once this many of the sentinel slice's 64 lanes carry the tag (0 = all of them)
-#endif
-#ifndef CS_SSLEEP
-#define CS_SSLEEP 1   // s_sleep units between two sentinel looks
-#endif
-#ifndef CS_DELAY
-#define CS_DELAY 4
-#endif
-#ifndef CS_YIELD
-#define CS_YIELD 0
-#endif
-#ifndef CS_LATE_H1
-#define CS_LATE_H1 1   // 1 = the S waves gather h1' BEHIND barrier B1 (one look, the data is long there) and synchronise among themselves through LDS flags
+#define CS_EARLY_LOOK 8  // the full look goes out once this many of the sentinel slice's 64 lanes hold data (0 = all of them)
 #endif
 #ifndef CS_MAX_NQ
-#define CS_MAX_NQ 2   // row quads per team this file is built for
+#define CS_MAX_NQ 2      // row quads per team this file is built for
 #endif
 
 namespace {
+
+constexpr unsigned CS_EMPTY = 0xffffffffu;   // a mailbox word nobody has published yet (see the protocol above)
 
 template <int NQ>
 struct LayCS {
@@ -131,141 +128,80 @@ struct LayCS {
     static constexpr int L_Q = L_P + VEC;           // x3
     static constexpr int L_H1 = L_Q + VEC;          // h1', later fc1 outputs
     static constexpr int L_XN = L_H1 + VEC;
-    static constexpr int L_LG = L_H1;               // [R][32] MOL: the 30 fc3 outputs of every batch row, in window 5 (H1 is dead from B4 to the next h1' gather)
+    static constexpr int L_LG = L_H1;               // [R][32] MOL: the 30 fc3 outputs of every batch row, in window 5 (H1 is dead from B4 to the next pair gather)
     static constexpr int L_MISC = L_XN + 16;
     static constexpr int L_PROF = L_MISC + 16;      // [2 roles][24]: phase cycles of wave 0 (C) and wave 4 (S), instrumented build only
     static constexpr int L_TOTAL = L_PROF + 48;
     static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
     static_assert((L_P % 4) == 0, "B operands are read as 16-byte vectors");
+    // mailbox regions per team, in 4-byte words; every region is double-buffered by step parity
+    static constexpr unsigned RGD = (unsigned)VEC;                       // one published vector of words
+    static constexpr unsigned M_XH = 0;                                  // {x2, h1'} pairs: 2 parities x 2 RGD
+    static constexpr unsigned M_X3 = 4 * RGD, M_F1 = 6 * RGD, M_F2 = 8 * RGD;   // 2 parities x RGD each
+    static constexpr unsigned M_PR = 10 * RGD;                           // race candidates: 2 parities x PRG granules of 8 bytes
+    static constexpr unsigned PRG = (unsigned)R * 256u;                  // [row][32 workgroups][8 waves]
+    static constexpr unsigned MAIL_WORDS = M_PR + 2 * 2 * PRG;
+    static_assert(MAIL_WORDS <= 2 * WRNN_BATCH_MAIL_GRANULES, "mailbox budget");
+    static constexpr int NMP = R;                   // 16-byte loads per thread (256 threads) of a pair vector
+    static constexpr int NMW = R / 2;               //                                          of a word vector
 };
 // hand-over slots
 constexpr int H_GH1R = 0, H_GH1Z = 1, H_GH1N = 2, H_CDX = 3, H_CDY = 4, H_CDZ = 5, H_CDW = 6, H_GH2R = 7, H_GH2Z = 8, H_GH2N = 9,
               H_C2R = 10, H_C2Z = 11, H_C2N = 12, H_C3 = 13, H_C4 = 14, H_NZ = 15;   // H_NZ: [parity][2]
 
-// sentinel first, then everything: a C / S wave has nothing to do between its publish and this gather, and a poll that opens with a
-// full look re-reads R x 4 KB per workgroup while the producers' stores queue behind those reads
-// CS_ROT (developer knob): register m of a thread holds slice (m + rot) & (NM - 1): the workgroups / waves of a team start their look at
-// different slices, so that at any instant their requests are spread over the L2 channels instead of all asking for slice 0 first
-// CS_DIAG 4 / 8 (timing diagnostics, wrong results): a look fetches 3/4 / 1/2 of its slices (the sentinel slice NM - 1 is always among them)
-__device__ __forceinline__ constexpr bool diag_skip(int m) { return CS_DIAG == 4 ? (m & 3) == 2 : CS_DIAG == 8 ? (m & 1) == 0 : false; }
-// CS_DIAG 16 / 32 / 64 (timing diagnostics, wrong results): the S waves' W_hh1 product with (16) two v_fma per MFMA instead of the MFMA, (32) its B operands
-// read from LDS once in front of the loop instead of slab by slab, (64) one A register for all MFMAs -- which property of the product slows the C wave's look?
-template <int NQ, int V>
-__device__ __forceinline__ void diag_gates(const float *w, lds_cf4p xv, f4 (&acc)[3][NQ]) {
-    f4 b0[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) b0[q] = xv[(q * 8) * 64];
-#pragma unroll
-    for (int S = 0; S < 8; ++S) {
-        f4 b[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = V == 32 ? b0[q] : xv[(q * 8 + S) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int gt = 0; gt < 3; ++gt) {
-                const float wa = V == 64 ? w[0] : w[gt * 32 + 4 * S + e];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (V == 16) { acc[gt][q].x = fmaf(wa, b[q][e], acc[gt][q].x); acc[gt][q].y = fmaf(wa, b[q][e], acc[gt][q].y); }
-                    else acc[gt][q] = mfma4(wa, b[q][e], acc[gt][q]);
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+__device__ __forceinline__ void st_word(unsigned *base, unsigned idx, unsigned v) {
+    const unsigned off = idx * 4u;
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
-template <int NM>
-__device__ __forceinline__ void gather_rot(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], unsigned rot, bool &dead,
-                                           unsigned *err, unsigned code, unsigned *rounds = nullptr, unsigned *fine = nullptr) {
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-        if (!diag_skip(m)) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
-    if (fine) {   // instrumented build (CS_PROF_FINE): when the FIRST load of the data look is back
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NM - 1) : "memory");
-        fine[0] = (unsigned)__builtin_readcyclecounter();
-    }
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-        if (diag_skip(m)) g[0][m] = g[0][CS_DIAG == 4 ? m - 1 : (m | 1)];
+__device__ __forceinline__ void st_pair(unsigned *base, unsigned idx, unsigned lo, unsigned hi) {   // idx: word index of the pair (even)
+    const u64 v = ((u64)hi << 32) | lo;
+    const unsigned off = idx * 4u;
+    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+// has every word of a 16-byte load arrived?  (a pair arrives whole: one 8-byte store -- its first word stands for both)
+template <bool PAIR>
+__device__ __forceinline__ bool arrived(const u4v &v) {
+    return PAIR ? (v.x != CS_EMPTY && v.z != CS_EMPTY) : (v.x != CS_EMPTY && v.y != CS_EMPTY && v.z != CS_EMPTY && v.w != CS_EMPTY);
+}
+// All-gather of one published vector: NL 16-byte sc1 loads per thread (voff = thread * 16, soff = the vector's byte offset).
+// Sentinel first, then everything: a C wave has nothing (or little) to do between its publish and this gather, and a poll that opens
+// with a full look re-reads the whole vector per workgroup while the producers' stores queue behind those reads.
+// The sentinel is the vector's last 4 KB (words of all 32 producers); the full look goes out as soon as CS_EARLY_LOOK of its 64 lanes hold
+// data: the stragglers' words land while it is in flight, so the sentinel round trip and the data round trip overlap (round 4: +2.1 % /
+// +4.4 %).  A look that still comes back incomplete polls the sentinel until it is complete and then fetches everything again: no
+// per-slice state (the retry masks of the first version cost ~16 SGPR pairs).  Every spin is bounded.
+typedef volatile int __attribute__((address_space(3))) *lds_vip;
+template <int NL, bool PAIR, bool SENTINEL = true>
+__device__ __forceinline__ void gather_words(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u4v (&g)[NL], bool &dead, unsigned *err, unsigned code,
+                                             unsigned *sent_cyc = nullptr, lds_vip hold = nullptr) {
     unsigned spins = 0;
-    for (;;) {
-        bool ok = true;
-#if CS_MINCHK
-        {   // a tag is never AHEAD of the step (nobody can publish step e + 2 into this parity while somebody still looks for e): all fresh <=> min == tag
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned mn = 0xffffffffu;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) { const unsigned a = mn < g[0][m].y ? mn : g[0][m].y; mn = a < g[0][m].w ? a : g[0][m].w; }
-            ok = mn == tag;
-        }
+    while (SENTINEL) {
+        const u4v sv = ld_pair(rs, voff, soff + (NL - 1) * 4096u);
+#if CS_EARLY_LOOK
+        if (__builtin_popcountll(__ballot(arrived<PAIR>(sv))) >= CS_EARLY_LOOK || dead) break;
 #else
-#pragma unroll
-        for (int m = 0; m < NM; ++m) ok = ok && g[0][m].y == tag && g[0][m].w == tag;
+        if (__all(arrived<PAIR>(sv)) || dead) break;
 #endif
-        if (rounds) *rounds += 1000u;   // instrumented build: data looks of this exchange, x 1000
-        if (fine) fine[1] = (unsigned)__builtin_readcyclecounter();   // ... and when all of them are back and checked
+        if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (sent_cyc) *sent_cyc = (unsigned)__builtin_readcyclecounter();   // instrumented build: the sentinel wait ends here, the data look starts
+    if (hold && (threadIdx.x & 63) == 0) *hold = 0;                      // CS_YIELD 2: the S wave of this SIMD holds its MFMAs while the look is checked and written
+    for (;;) {
+#pragma unroll
+        for (int m = 0; m < NL; ++m) g[m] = ld_pair(rs, voff, soff + m * 4096u);
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < NL; ++m) ok = ok && arrived<PAIR>(g[m]);
         if (__all(ok) || dead) break;
         for (;;) {
             if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
             __builtin_amdgcn_s_sleep(1);
-            const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
-            if (__all(sv.y == tag && sv.w == tag)) break;
+            const u4v sv = ld_pair(rs, voff, soff + (NL - 1) * 4096u);
+            if (__all(arrived<PAIR>(sv))) break;
         }
         if (dead) break;
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-            if (!diag_skip(m)) g[0][m] = ld_pair(rs, voff, soff + ((m + rot) & (NM - 1)) * 4096u);
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-            if (diag_skip(m)) g[0][m] = g[0][CS_DIAG == 4 ? m - 1 : (m | 1)];
     }
-}
-template <int NM>
-__device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], bool &dead,
-                                          unsigned *err, unsigned code, volatile int *seen = nullptr, unsigned rot = 0, unsigned *sent_cyc = nullptr, unsigned *rounds = nullptr, unsigned *fine = nullptr) {
-#if CS_GATHER == 0
-    unsigned spins = 0;
-    for (;;) {
-        const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
-#if CS_EARLY_LOOK
-        // developer knob: the full look goes out as soon as CS_EARLY_LOOK of the sentinel slice's 64 lanes carry the step's tag (the
-        // stragglers' granules land while it is in flight)
-        if (__builtin_popcountll(__ballot(sv.y == tag && sv.w == tag)) >= CS_EARLY_LOOK || dead) break;
-#else
-        if (__all(sv.y == tag && sv.w == tag) || dead) break;
-#endif
-        if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
-#if CS_SSLEEP
-        __builtin_amdgcn_s_sleep(CS_SSLEEP);
-#endif
-    }
-#elif CS_GATHER == 2
-    __builtin_amdgcn_s_sleep(CS_DELAY);
-#elif CS_GATHER == 3
-    // two sentinel looks in flight, half a round trip apart: the arrival is noticed ~a quarter of a round trip after it happened instead of ~half
-    {
-        unsigned spins = 0;
-        u4v s0 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
-        for (;;) {
-            __builtin_amdgcn_s_sleep(CS_DELAY);
-            const u4v s1 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
-            if (__builtin_popcountll(__ballot(s0.y == tag && s0.w == tag)) >= (CS_EARLY_LOOK ? CS_EARLY_LOOK : 64) || dead) break;
-            __builtin_amdgcn_s_sleep(CS_DELAY);
-            s0 = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
-            if (__builtin_popcountll(__ballot(s1.y == tag && s1.w == tag)) >= (CS_EARLY_LOOK ? CS_EARLY_LOOK : 64)) break;
-            if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
-        }
-    }
-#endif
-    if (sent_cyc) *sent_cyc = (unsigned)__builtin_readcyclecounter();   // instrumented build: the sentinel wait ends here, the data look starts
-    if (seen && (threadIdx.x & 63) == 0) *seen = (int)tag;   // "the data is there, my full look goes out now" (CS_LATE_H1 2: the S wave's look follows)
-#if CS_ROT || CS_DIAG >= 4 || CS_PROF_ROUNDS || CS_PROF_FINE || CS_MINCHK
-    gather_rot<NM>(rs, voff, soff, tag, g, rot, dead, err, code, rounds, fine);
-#else
-    const unsigned offs[1] = {soff};
-    gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
-#endif
 }
 
 // one set of 4 fc3 rows (A-operand image `w3s` in LDS: [8 slabs][64 lanes] f4) times the gathered fc2 outputs: the thread's folded logit
@@ -314,6 +250,40 @@ __device__ __forceinline__ float fc3_one_set(lds_cf4p w3s, lds_cf4p xv, int my_r
     return lg;
 }
 
+// RAW sampler, in-wave part: (v, k) = score and class of this lane's candidate for its batch row -> the best of the wave's classes for that row
+// (the four unit groups rho = lane >> 4), ties -> the lower class.  Valid in the lanes with rho == 0.
+__device__ __forceinline__ void race_fold(float &v, int &k) {
+    {
+        const u2v pv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const u2v pk = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
+        const int ka = (int)pk.x, kb = (int)pk.y;
+        const bool tb = vb > va || (vb == va && kb < ka);
+        v = tb ? vb : va; k = tb ? kb : ka;
+    }
+    {
+        const u2v pv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const u2v pk = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
+        const int ka = (int)pk.x, kb = (int)pk.y;
+        const bool tb = vb > va || (vb == va && kb < ka);
+        v = tb ? vb : va; k = tb ? kb : ka;
+    }
+}
+// ... and the winner among a row's 256 candidates {tag | class, score}: lane l holds slots 4 l .. 4 l + 3 (two 16-byte loads); slots are in class
+// order (workgroup, wave pair, C before S), so "the first of equal scores" is the lowest class, as torch's argmax of p / q picks it
+__device__ __forceinline__ int race_winner(const u4v &ga, const u4v &gb) {
+    float best = __uint_as_float(ga.x);
+    unsigned bk = ga.y;
+    { const float v = __uint_as_float(ga.z); if (v > best) { best = v; bk = ga.w; } }
+    { const float v = __uint_as_float(gb.x); if (v > best) { best = v; bk = gb.y; } }
+    { const float v = __uint_as_float(gb.z); if (v > best) { best = v; bk = gb.w; } }
+    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
+    const u64 ball = __ballot(best == mx);
+    const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
+    return __builtin_amdgcn_readlane((int)(bk & 1023u), src);
+}
+
 }  // namespace
 
 #define PBW(i)                                                                 \
@@ -338,12 +308,13 @@ __device__ __forceinline__ float fc3_one_set(lds_cf4p w3s, lds_cf4p xv, int my_r
 
 template <int MODE, int NQ, bool PROF>
 __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs a) {
-    typedef Lay<NQ> LM;       // mailbox regions (shared with loop_batch.hip)
     typedef LayCS<NQ> L;
-    constexpr int R = L::R, NM = LM::NM, SL = L::SL;
+    constexpr int R = L::R, NMP = L::NMP, NMW = L::NMW, SL = L::SL;
     constexpr int DG = NQ == 1 ? 2 : 1, DS = NQ == 1 ? 4 : 2, D3 = NQ == 1 ? 2 : 1;
+    // fc3: the 8 sets of four rows a SIMD owns are shared between its two waves -- the C wave evaluates classes 8 wl + iu, the S wave 8 wl + iu + 4
+    // (the fc3 image is in LDS, so either wave can): half the MFMAs each, side by side on the matrix pipe, instead of all of them in the C wave
+    constexpr bool FC3_SPLIT = MODE == WRNN_MODE_MOL ? CS_FC3_SPLIT != 0 : CS_FC3_SPLIT_RAW != 0;
     // rows whose race a C wave finishes itself: RAW at 8 rows per team hands the second one (batch row wl + 4) to the S wave of its SIMD
-    constexpr bool FC3_SPLIT = MODE == WRNN_MODE_MOL && CS_FC3_SPLIT;
     constexpr int NBC = (MODE == WRNN_MODE_RAW && NQ == 2 && CS_SPLIT_WIN) ? 1 : NQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
@@ -401,6 +372,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const int n_batches = (a.n_rows + a.rpb - 1) / a.rpb;
     if (g >= TB_WGS || team >= a.n_teams || team >= n_batches) return;
     u64 *mail = a.mail + (size_t)team * WRNN_BATCH_MAIL_GRANULES;
+    unsigned *mailw = (unsigned *)mail;   // the same bytes in words (pairs and words: LayCS::M_*; the race candidates stay 8-byte granules)
     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)mail, 0, (int)(WRNN_BATCH_MAIL_GRANULES * 8u), 0x00020000);
 
     const int unit = 16 * g + 4 * wl + iu;
@@ -412,7 +384,6 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const bool wg_has_fc3 = MODE == WRNN_MODE_MOL || 32 * g < NC;
     const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
     const unsigned gvoff = (unsigned)tl * 16u;
-    const unsigned rot = CS_ROT ? (unsigned)__builtin_amdgcn_readfirstlane((g * 5 + wave * 3) & (NM - 1)) : 0u;   // CS_ROT: where this wave's looks start
     // compact slot index of this thread's (unit, row): duplicates (kp2 >= NQ) read their primary lane's entry (an LDS broadcast)
     const int ci = (wl * 4 + rho) * (4 * NQ) + my_rq * 4 + j;
 
@@ -420,15 +391,19 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     //      [96,192) | W_hh2 r,z [192,256).  Gate n of W_hh2 and the fc3 slice are A-operand images in LDS.
     float wv[160];
     {
-        const float *src = a.batch_w + (((size_t)g * 4 + wl) * 320) * 64 + lane;
+        // buffer loads: the wave-uniform part of every address (the weight's index) is the instruction's scalar / immediate offset.  As
+        // `src[i * 64]` global loads the 160 offsets became 160 64-bit scalar constants that hipcc kept live and spilled into VGPR lanes:
+        // ~590 SGPR spills = 10 of the wave's 256 VGPRs reserved as spill space for the whole kernel (round-5 ISA census).
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.batch_w + (((size_t)g * 4 + wl) * 320) * 64), 0, 320 * 64 * 4, 0x00020000);
+        const unsigned wvo = (unsigned)lane * 4u;
         if (isC) {
 #pragma unroll
-            for (int i = 0; i < 96; ++i) wv[i] = src[(size_t)i * 64];
+            for (int i = 0; i < 96; ++i) wv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, wvo, (unsigned)i * 256u, 0));
 #pragma unroll
-            for (int i = 0; i < 64; ++i) wv[96 + i] = src[(size_t)(256 + i) * 64];
+            for (int i = 0; i < 64; ++i) wv[96 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, wvo, (unsigned)(256 + i) * 256u, 0));
         } else {
 #pragma unroll
-            for (int i = 0; i < 160; ++i) wv[i] = src[(size_t)(96 + i) * 64];
+            for (int i = 0; i < 160; ++i) wv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, wvo, (unsigned)(96 + i) * 256u, 0));
         }
         const float4 *f3 = (const float4 *)(a.batch_fc3 + (size_t)(MODE == WRNN_MODE_MOL ? 0 : g) * 16384);
         float4 *dst = (float4 *)(lds + L::L_FC3);
@@ -455,13 +430,25 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const lds_cfp cst = (lds_cfp)(size_t)launder(smem_base + (unsigned)L::L_CST * 4u + (unsigned)ci * 4u);
     typedef float __attribute__((address_space(3))) *lds_fp;
     const lds_fp hand = (lds_fp)(size_t)launder(smem_base + (unsigned)L::L_HAND * 4u + (unsigned)ci * 4u);
+    // where a thread's loads of a gathered vector go (B-operand order [rq][S][kp][j][e]; thread tl, 16-byte load m):
+    //   pairs (8-byte entries, mailbox order [rq][wl][S][iu][j][e]): load m = (rq, wl) = (m >> 2, m & 3), the thread's two entries are e, e + 1 -> one 8-byte write
+    //   words: load m covers (rq, wl) = (m >> 1, 2 (m & 1) + (tl >> 7)), the thread's four words are e = 0..3 -> one 16-byte write
     const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + 2u * (unsigned)(tl & 31)) * 4u);
+    typedef f4 __attribute__((address_space(3))) *lds_f4p;
+    const lds_f4p gd4 = (lds_f4p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)((tl >> 4) & 7) * 64u + (unsigned)(tl >> 7) * 16u + (unsigned)(tl & 15)) * 16u);
 
-    volatile int *tok = (volatile int *)(misc_i + 4 + wl);   // CS_YIELD: C wave wl -> S wave wl of the same SIMD: 1 = "in a dependent VALU chain, keep the matrix pipe free"
-    volatile int *tok2 = (volatile int *)(misc_i + 12 + wl);   // CS_LATE_H1 2: C wave wl -> S wave wl: epoch whose x2 has arrived (h1' was published with it)
-    volatile int *sflag = (volatile int *)(misc_i + 8);         // CS_LATE_H1: S-wave meeting point (epoch of the H1 each wave has written)
+    // LDS words two waves talk through, addressed in the LDS address space so that they are stored and polled with DS instructions (round-4
+    // advisor: through generic `volatile` pointers hipcc emitted flat_store / flat_load, which the memory model does not order against the
+    // ds_write of the data; a wave's DS instructions execute in order and the LDS serves the waves' instructions one after the other):
+    //   tok[wl]   CS_YIELD: C wave wl -> S wave wl of the same SIMD: 1 = "I multiply or wait for a sentinel: the matrix pipe is yours too", 0 = "hold"
+    //   sflag[4]  CS_PAIR 0: meeting point of the four S waves (epoch of the H1 each of them has written)
     typedef int i4v __attribute__((ext_vector_type(4)));
-    volatile i4v *sflag4 = (volatile i4v *)(misc_i + 8);
+    typedef volatile i4v __attribute__((address_space(3))) *lds_vi4p;
+    const lds_vip tok = (lds_vip)(size_t)(smem_base + (unsigned)(L::L_MISC + 4 + wl) * 4u);
+    const lds_vip sflag = (lds_vip)(size_t)(smem_base + (unsigned)(L::L_MISC + 8) * 4u);
+    auto tok_set = [&](int v) { if (CS_YIELD && lane == 0) *tok = v; };
+    const lds_vip hold2 = CS_YIELD == 2 ? tok : nullptr;
+    if (CS_YIELD && !isC && lane == 0) *tok = 1;
     bool dead = false;
     unsigned epoch = 0;
     unsigned *prof_lds = (unsigned *)(lds + L::L_PROF);
@@ -483,6 +470,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
         if (isC) {
             // =========================================== C: the serial chain ===========================================
             float h1 = 0.0f, h2 = 0.0f, x2own = 0.0f;
+            float gh2n = cst[C_H2N * SL];   // CS_WN_ON_C: gate n of W_hh2.h2' + b_hh2, evaluated by this wave a step ahead (step 0: h2 = 0, :194-196)
             int frow[NQ];
             int fsteps[NQ];
 #pragma unroll
@@ -509,20 +497,35 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     h1 = (1.0f - zg) * ng + zg * h1;
                     x2own = xin + h1;
                     if (primary) {
-                        st_granule(mail, LM::G_X2 + par * LM::RG + mb_own, epoch, __float_as_uint(x2own));
-                        st_granule(mail, LM::G_H1 + par * LM::RG + mb_own, epoch, __float_as_uint(h1));
+                        if (CS_PAIR) st_pair(mailw, L::M_XH + par * 2u * L::RGD + 2u * mb_own, __float_as_uint(x2own), __float_as_uint(h1));
+                        else {   // two word vectors: x2 for the C waves' look, h1' for the S waves' (behind B1)
+                            st_word(mailw, L::M_XH + par * 2u * L::RGD + mb_own, __float_as_uint(x2own));
+                            st_word(mailw, L::M_XH + par * 2u * L::RGD + L::RGD + mb_own, __float_as_uint(h1));
+                        }
                     }
                 }
                 PBW(0);
-                {
-                    u4v gx[1][NM];
+                if (CS_PAIR) {
+                    u4v gx[NMP];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u, CS_LATE_H1 == 2 ? tok2 : nullptr, rot GSF_TS);
+                    gather_words<NMP, true>(mrs, gvoff, (L::M_XH + par * 2u * L::RGD) * 4u, gx, dead, a.err, 21u GSF_TS);
                     GSF_ACC(17);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(0 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
+                    for (int m = 0; m < NMP; ++m) {   // x2 -> P, h1' -> H1 (the S waves multiply it from B1 on)
+                        gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[m].x), __uint_as_float(gx[m].z)};
+                        gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[m].y), __uint_as_float(gx[m].w)};
+                    }
+                } else {
+                    u4v gx[NMW];
+                    GSF_DECL;
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_XH + par * 2u * L::RGD) * 4u, gx, dead, a.err, 21u GSF_TS);
+                    GSF_ACC(17);
+                    PBW(1);
+#pragma unroll
+                    for (int m = 0; m < NMW; ++m) gd4[0 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
+                tok_set(1);
                 PBW(2);
                 __syncthreads();   // B1
                 PBW(3);
@@ -535,7 +538,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                     mfma_gates<NQ, 3, false, DG>(wv, vP, acc, NoMid());
-                    if (CS_YIELD == 1 && lane == 0) *tok = 1;   // the fold and the gates are a dependent VALU chain: the shadow wave's MFMAs wait
+                    tok_set(0);   // the fold and the gates are a dependent VALU chain: beside an MFMA stream they take three times as long (session 1)
                     PBW(4);
                     float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -546,22 +549,36 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     PBW(5);
                     const float rg = sigmoid_fast((tr + hand[H_C2R * SL]) + hand[H_GH2R * SL]);
                     const float zg = sigmoid_fast((tz + hand[H_C2Z * SL]) + hand[H_GH2Z * SL]);
-                    const float ng = tanh_fast((tn + hand[H_C2N * SL]) + rg * hand[H_GH2N * SL]);
+                    const float ng = tanh_fast((tn + hand[H_C2N * SL]) + rg * (CS_WN_ON_C ? gh2n : hand[H_GH2N * SL]));
                     h2 = (1.0f - zg) * ng + zg * h2;
                     const float x3 = x2own + h2;
-                    if (primary) st_granule(mail, LM::G_X3 + par * LM::RG + mb_own, epoch, __float_as_uint(x3));
-                    if (CS_YIELD == 1 && lane == 0) *tok = 0;
+                    if (primary) {
+                        st_word(mailw, L::M_X3 + par * L::RGD + mb_own, __float_as_uint(x3));
+                        // everybody has published the pairs of this step, i.e. finished every read of the previous one: its words (other parity)
+                        // are emptied by their producer, in the same store round trip as the publish (see the protocol at the top)
+                        const unsigned op = par ^ 1u;
+                        if (CS_PAIR) st_pair(mailw, L::M_XH + op * 2u * L::RGD + 2u * mb_own, CS_EMPTY, CS_EMPTY);
+                        else { st_word(mailw, L::M_XH + op * 2u * L::RGD + mb_own, CS_EMPTY); st_word(mailw, L::M_XH + op * 2u * L::RGD + L::RGD + mb_own, CS_EMPTY); }
+                        st_word(mailw, L::M_X3 + op * L::RGD + mb_own, CS_EMPTY);
+                        st_word(mailw, L::M_F1 + op * L::RGD + mb_own, CS_EMPTY);
+                        st_word(mailw, L::M_F2 + op * L::RGD + mb_own, CS_EMPTY);
+                    }
+                    tok_set(1);   // from here the wave waits for a sentinel
                 }
                 PBW(6);
                 {
-                    u4v gx[1][NM];
+                    u4v gx[NMW];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X3 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 23u, CS_YIELD == 2 ? tok : nullptr, rot GSF_TS);
-                    if (CS_YIELD == 2 && lane == 0) *tok = 0;   // the look is back: the shadow wave's MFMAs go on
+#if CS_PROF_SPLIT
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_X3 + par * L::RGD) * 4u, gx, dead, a.err, 23u GSF_TS, hold2);
+#else
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_X3 + par * L::RGD) * 4u, gx, dead, a.err, 23u, nullptr, hold2);
+#endif
                     GSF_ACC(7);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(1 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
+                    for (int m = 0; m < NMW; ++m) gd4[1 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
+                tok_set(1);
                 PBW(9);
                 __syncthreads();   // B2
                 PBW(10);
@@ -570,24 +587,69 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 {
                     f4 sum[NQ];
                     mfma_single<NQ, (NQ == 1 ? 4 : 2), false, DS>(wv + 96, vQ, sum);
+                    tok_set(0);
                     float s = 0.f;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const float f = fold_kp(sum[q]);
                         if (q == 0 || my_rq == q) s = f;
                     }
-                    if (primary) st_granule(mail, LM::G_F1 + par * LM::RG + mb_own, epoch, __float_as_uint(fmaxf(s + hand[H_C3 * SL], 0.0f)));
+                    // the CS_EMPTY stores of window 2 have reached the L2 before anybody can poll their parity again (protocol, top of the file): the
+                    // x3 look behind them is long back, the wait is free
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (primary) st_word(mailw, L::M_F1 + par * L::RGD + mb_own, __float_as_uint(fmaxf(s + hand[H_C3 * SL], 0.0f)));
+                    tok_set(1);
                 }
                 PBW(11);
+                if (CS_WN_ON_C) {
+                    // gate n of gh2' = W_hh2.(x3 - x2) + b_hh2 for the NEXT step (A operands: the LDS image of the S waves' round-4 product), while the
+                    // fc1 words travel: a publish is visible everywhere ~600-800 cycles after the store at the earliest, these 32 NQ MFMAs + fold take
+                    // about that.  Q (x3) and P (x2) are both intact in window 3.
+                    __builtin_amdgcn_sched_barrier(0);
+                    f4 accn[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) accn[q] = (f4){0.f, 0.f, 0.f, 0.f};
+                    f4 xq[NQ], xp[NQ], wn = wnl[0];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
+#pragma unroll
+                    for (int S = 0; S < 8; ++S) {
+                        f4 b[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
+                        const f4 wcur = wn;
+                        if (S < 7) {
+                            wn = wnl[(S + 1) * 64];
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8 + S + 1) * 64]; xp[q] = vP[(q * 8 + S + 1) * 64]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) accn[q] = mfma4(wcur[e], b[q][e], accn[q]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float fn = fold_kp(accn[q]);
+                        if (q == 0 || my_rq == q) gh2n = fn + cst[C_H2N * SL];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 {
-                    u4v gx[1][NM];
+                    u4v gx[NMW];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 24u, CS_YIELD == 2 ? tok : nullptr, rot GSF_TS);
-                    if (CS_YIELD == 2 && lane == 0) *tok = 0;
+#if CS_PROF_SPLIT
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_F1 + par * L::RGD) * 4u, gx, dead, a.err, 24u GSF_TS, hold2);
+#else
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_F1 + par * L::RGD) * 4u, gx, dead, a.err, 24u, nullptr, hold2);
+#endif
                     GSF_ACC(12);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(2 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
+                    for (int m = 0; m < NMW; ++m) gd4[2 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
+                tok_set(1);
                 PBW(13);
                 __syncthreads();   // B3
                 PBW(14);
@@ -602,16 +664,16 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         const float f = fold_kp(sum[q]);
                         if (q == 0 || my_rq == q) s = f;
                     }
-                    if (primary) st_granule(mail, LM::G_F2 + par * LM::RG + mb_own, epoch, __float_as_uint(fmaxf(s + hand[H_C4 * SL], 0.0f)));
+                    if (primary) st_word(mailw, L::M_F2 + par * L::RGD + mb_own, __float_as_uint(fmaxf(s + hand[H_C4 * SL], 0.0f)));
                 }
                 PBW(15);
                 {
-                    u4v gx[1][NM];
+                    u4v gx[NMW];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u, nullptr, rot GSF_TS);
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_F2 + par * L::RGD) * 4u, gx, dead, a.err, 25u GSF_TS);
                     GSF_ACC(16);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(0 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
+                    for (int m = 0; m < NMW; ++m) gd4[0 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
                 PBW(18);
                 __syncthreads();   // B4
@@ -621,10 +683,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 {
                     float lg0 = 0.f, lg1 = 0.f;
                     if (FC3_SPLIT) {
-                        // MOL: the 8 sets of four fc3 rows are shared between the two waves of a SIMD -- this wave evaluates classes 8 wl + iu,
-                        // the S wave 8 wl + iu + 4 (the fc3 image is in LDS, so either wave can): 32 MFMAs each, side by side, instead of 64 here
-                        lg0 = fc3_one_set<NQ, D3>(w3, vP, my_rq) + cst[C_B30 * SL];
-                        if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 < NC)
+                        // this wave's half: classes 8 wl + iu of the workgroup's slice (RAW) / of all 30 rows (MOL); the S wave of the SIMD: + 4
+                        if (wg_has_fc3) lg0 = fc3_one_set<NQ, D3>(w3, vP, my_rq) + cst[C_B30 * SL];
+                        if (a.logits_out && primary && row_ok && t < rw.steps && (MODE != WRNN_MODE_MOL || g == 0) && cls0 < NC)
                             a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0] = lg0;
                     } else if (wg_has_fc3) {
                         constexpr int NP = NQ == 1 ? 2 : 1;
@@ -680,30 +741,18 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     }
                     if (MODE == WRNN_MODE_RAW) {
                         const lds_fp hz = hand + (H_NZ + 2 * par) * SL;
-                        const float nz0 = hz[0], nz1 = hz[SL];
-                        float v = cls0 < NC ? lg0 + nz0 : -INFINITY;
+                        float v = cls0 < NC ? lg0 + hz[0] : -INFINITY;
                         int k = cls0;
-                        const float v1 = cls0 + 4 < NC ? lg1 + nz1 : -INFINITY;
-                        if (v1 > v) { v = v1; k = cls0 + 4; }
-                        {
-                            const u2v pv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                            const u2v pk = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
-                            const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
-                            const int ka = (int)pk.x, kb = (int)pk.y;
-                            const bool tb = vb > va || (vb == va && kb < ka);
-                            v = tb ? vb : va; k = tb ? kb : ka;
+                        if (!FC3_SPLIT) {
+                            const float v1 = cls0 + 4 < NC ? lg1 + hz[SL] : -INFINITY;
+                            if (v1 > v) { v = v1; k = cls0 + 4; }
                         }
-                        {
-                            const u2v pv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                            const u2v pk = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
-                            const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
-                            const int ka = (int)pk.x, kb = (int)pk.y;
-                            const bool tb = vb > va || (vb == va && kb < ka);
-                            v = tb ? vb : va; k = tb ? kb : ka;
+                        race_fold(v, k);
+                        if (primary && rho == 0) {
+                            const unsigned slot = L::M_PR / 2u + par * L::PRG + (unsigned)rb * 256u + (unsigned)(g * 8 + wl * 2);
+                            st_granule(mail, slot, (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
+                            if (!FC3_SPLIT) st_granule(mail, slot + 1u, (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));   // the S wave's slot
                         }
-                        if (primary && rho == 0)
-                            st_granule(mail, LM::G_PR + par * LM::PRG + (unsigned)rb * 128u + (unsigned)(g * 4 + wl),
-                                       (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
                     } else {
                         // MOL: the wave's 8 fc3 outputs of every batch row -> LDS; wave w samples batch rows w, w + 4 behind the barrier
                         if (primary) { lgt[rb * 32 + cls0] = lg0; if (!FC3_SPLIT) lgt[rb * 32 + cls0 + 4] = lg1; }
@@ -711,16 +760,21 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 }
                 PBW(20);
                 if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b
-                u4v gqa[NBC];
+                u4v gqa[NBC][2];
                 if (MODE == WRNN_MODE_RAW) {
                     const unsigned tg = epoch & 0x3fffffu;
                     unsigned spins = 0;
                     for (;;) {
 #pragma unroll
-                        for (int i = 0; i < NBC; ++i) gqa[i] = ld_pair(mrs, (unsigned)lane * 16u, (LM::G_PR + par * LM::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u);
+                        for (int i = 0; i < NBC; ++i) {
+                            const unsigned cb = (L::M_PR / 2u + par * L::PRG + (unsigned)(wl + 4 * i) * 256u) * 8u;
+                            gqa[i][0] = ld_pair(mrs, (unsigned)lane * 32u, cb);
+                            gqa[i][1] = ld_pair(mrs, (unsigned)lane * 32u, cb + 16u);
+                        }
                         bool ok = true;
 #pragma unroll
-                        for (int i = 0; i < NBC; ++i) ok = ok && (gqa[i].y >> 10) == tg && (gqa[i].w >> 10) == tg;
+                        for (int i = 0; i < NBC; ++i)
+                            ok = ok && (gqa[i][0].y >> 10) == tg && (gqa[i][0].w >> 10) == tg && (gqa[i][1].y >> 10) == tg && (gqa[i][1].w >> 10) == tg;
                         if (__all(ok) || dead) break;
                         if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 26u); break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -743,15 +797,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     float x_new;
                     int lab;
                     if (MODE == WRNN_MODE_RAW) {
-                        const u4v gq = gqa[bi];
-                        const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
-                        const bool pb = vb > va;
-                        const float best = pb ? vb : va;
-                        const int besti = (int)((pb ? gq.w : gq.y) & 1023u);
-                        const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
-                        const u64 ball = __ballot(best == mx);
-                        const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
-                        lab = __builtin_amdgcn_readlane(besti, src);
+                        lab = race_winner(gqa[bi][0], gqa[bi][1]);
                         x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
                     } else {
                         // sample_from_discretized_mix_logistic (distribution.py:87-123) for batch row `brow`
@@ -888,7 +934,6 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
             }
             cond_step(0);
             frame_flush();
-            if (!CS_NOISE_W1) noise_step(0, (epoch + 1) & 1u);
             __syncthreads();
 
             for (int64_t t = 0; t < bsteps; ++t) {
@@ -896,72 +941,53 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 const unsigned par = epoch & 1u;
                 if (PROF) prof_last = (unsigned)__builtin_readcyclecounter();
 
-                // ---------------- window 1: gather h1' -> H1 ----------------
-                if (!CS_LATE_H1) {
-                    u4v gx[1][NM];
-                    gather_sf<NM>(mrs, gvoff, (LM::G_H1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 22u);
-                    PBW(1);
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(2 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
-                }
-                // the sampler's noise of THIS step, while the C waves wait for x2 (an S wave has nothing else to do before B1; in window 4,
-                // behind the W_hh2 fold, it made the S waves late at B4)
-                if (CS_NOISE_W1) noise_step(t, par);
-                u4v gxe[1][NM];
-                if (CS_LATE_H1 == 2) {
-                    // the look goes out as soon as the C wave of this SIMD has seen x2 arrive (h1' was published in the same instant) and has
-                    // issued its own look: the port serves that one first, this one right behind it, and the data waits in registers for B1
-                    for (unsigned sp = 0; sp < 400000u && *tok2 != (int)epoch && !dead; ++sp) __builtin_amdgcn_s_sleep(1);
-                    const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
-                    gather_issue<NM, 1>(mrs, gvoff, offs, gxe);
-                }
+                // ---------------- window 1: the sampler's noise of THIS step, while the C waves wait for the {x2, h1'} pairs (an S wave has nothing
+                // else to do before B1; in window 4 of the step before it made the S waves late at B4) ----------------
+                noise_step(t, par);
                 PBW(2);
-                __syncthreads();   // B1
+                __syncthreads();   // B1: the C waves have written x2 -> P and h1' -> H1
                 PBW(3);
-                if (CS_LATE_H1 == 2) {
-                    const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
-                    gather_vecs<NM, 1, true>(mrs, gvoff, offs, epoch, gxe, dead, a.err, 22u);
-                    PBW(1);
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gxe[0][m].x), __uint_as_float(gxe[0][m].z)};
-                    if (lane == 0) sflag[wl] = (int)epoch;
-                    for (unsigned sp = 0; sp < 200000u; ++sp) {
-                        const i4v f = *sflag4;
-                        if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
-                    }
-                }
-                if (CS_LATE_H1 == 1) {
-                    if (CS_SPRIO) __builtin_amdgcn_s_setprio(3);   // developer knob: the gather + meeting point at the C waves' priority
-                    // h1' is not needed before this wave's own W_hh1 product: fetched HERE, the S waves are never the last to reach B1 (they
-                    // were: their 32 KB look ran beside the C waves' x2 look through the same 64 B/clk port) and the x2 look has the port
-                    // to itself.  The four S waves then meet through LDS flags (s_barrier would need the C waves).
-                    u4v gx[1][NM];
-                    const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
-                    if (CS_ROT || CS_DIAG >= 4 || CS_MINCHK) gather_rot<NM>(mrs, gvoff, offs[0], epoch, gx, rot, dead, a.err, 22u);
-                    else gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
-                    PBW(1);
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) { const unsigned sm = CS_ROT ? ((unsigned)m + rot) & (unsigned)(NM - 1) : (unsigned)m; gdst[(2 * L::VEC + (sm >> 2) * 2048 + (sm & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)}; }
-                    if (lane == 0) sflag[wl] = (int)epoch;
-                    PBW(5);   // h1' written to LDS
-                    for (unsigned sp = 0; sp < 200000u; ++sp) {
-                        const i4v f = *sflag4;
-                        if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
-                    }
-                    PBW(6);   // the four S waves have met
-                    if (CS_SPRIO) __builtin_amdgcn_s_setprio(0);
-                }
 
-                // ---------------- windows 2 - 4: gh1' = W_hh1 . h1' + b_hh1 and gh2' = W_hh2 . (x3 - x2) + b_hh2 of the next step ----------------
-                // The MFMAs of a product run in "its" window (they read H1 resp. Q / P, which the C waves overwrite at the end of the next
-                // one); its FOLD -- pure register work, ~700 cycles at 8 rows -- runs behind the barrier, at the start of the next window:
-                // with the fold in front of B2 the S waves were the last to arrive there (B2 wait of the C waves 390 cycles + a stretched
-                // x3 exchange), and the same at B3.  The hand-over slots are read by C a whole step later.
-                f4 acc1[3][NQ], acc2[3][NQ];
+                // ---------------- window 2: gh1' = W_hh1 . h1' + b_hh1 of the next step, from B1 on, beside the C waves' phase-B MFMAs (two waves
+                // keep the SIMD's matrix pipe busier than one: 4 instead of 8 cycles per MFMA, bench_micro/mfma4_probe): the product is over long
+                // before the C waves' x3 look goes out -- a look beside a multiplying neighbour comes back when the neighbour's MFMA stream ends
+                // (profiles/r04_batch_cs_experiments.txt, last section).  The fold follows at once: the S waves wait at B2 anyway. ----------------
+                // an S wave looks at the token of the C wave it shares the SIMD with in front of every slab (CS_YIELD)
+                auto yield = [&]() {
+                    if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok == 0; ++sp) __builtin_amdgcn_s_sleep(1); }
+                };
+                if (!CS_PAIR) {
+                    // h1' gathered by the S waves themselves, BEHIND B1 (round 4: their look no longer runs beside the C waves' x2 look through the same
+                    // 64 B/clk port, and they are never the last at B1).  The words were published a whole window ago: one look, no sentinel.  The four S
+                    // waves then meet through LDS flags (s_barrier would need the C waves).
+                    __builtin_amdgcn_s_setprio(3);
+                    u4v gx[NMW];
+                    gather_words<NMW, false, false>(mrs, gvoff, (L::M_XH + par * 2u * L::RGD + L::RGD) * 4u, gx, dead, a.err, 22u);
+                    PBW(1);
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt)
+                    for (int m = 0; m < NMW; ++m) gd4[2 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's part of H1 has left the DS queue
+                    if (lane == 0) sflag[wl] = (int)epoch;
+                    PBW(5);
+                    unsigned sp = 0;
+                    for (;;) {
+                        const i4v f = *(lds_vi4p)sflag;
+                        if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
+                        if (++sp > 200000u) { dead = true; if (lane == 0) atomicExch(a.err, 29u); break; }   // a lost S wave: reported, not multiplied through
+                    }
+                    asm volatile("" ::: "memory");
+                    PBW(6);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                constexpr int NG2 = CS_WN_ON_C ? 2 : 3;
+                f4 acc1[3][NQ], acc2[NG2][NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) { acc1[gt][q] = (f4){0.f, 0.f, 0.f, 0.f}; acc2[gt][q] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) acc1[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int gt = 0; gt < NG2; ++gt) acc2[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
+                }
                 auto fold1 = [&]() {
                     float gr = 0.f, gz = 0.f, gn = 0.f;
 #pragma unroll
@@ -969,111 +995,116 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         const float fr = fold_kp(acc1[0][q]), fz = fold_kp(acc1[1][q]), fn = fold_kp(acc1[2][q]);
                         if (q == 0 || my_rq == q) { gr = fr + cst[C_H1R * SL]; gz = fz + cst[C_H1Z * SL]; gn = fn + cst[C_H1N * SL]; }
                     }
-                    if (primary) { hand[H_GH1R * SL] = gr; hand[H_GH1Z * SL] = gz; hand[H_GH1N * SL] = gn; }
+                    if (primary) { hand[H_GH1R * SL] = gr; hand[H_GH1Z * SL] = gz; hand[H_GH1N * SL] = gn; }   // read by C in phase A of the next step
                 };
                 auto fold2 = [&]() {
                     float gr = 0.f, gz = 0.f, gn = 0.f;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const float fr = fold_kp(acc2[0][q]), fz = fold_kp(acc2[1][q]), fn = fold_kp(acc2[2][q]);
-                        if (q == 0 || my_rq == q) { gr = fr + cst[C_H2R * SL]; gz = fz + cst[C_H2Z * SL]; gn = fn + cst[C_H2N * SL]; }
+                        const float fr = fold_kp(acc2[0][q]), fz = fold_kp(acc2[1][q]);
+                        if (q == 0 || my_rq == q) { gr = fr + cst[C_H2R * SL]; gz = fz + cst[C_H2Z * SL]; }
+                        if (!CS_WN_ON_C) { const float fn = fold_kp(acc2[NG2 - 1][q]); if (q == 0 || my_rq == q) gn = fn + cst[C_H2N * SL]; }
                     }
-                    if (primary) { hand[H_GH2R * SL] = gr; hand[H_GH2Z * SL] = gz; hand[H_GH2N * SL] = gn; }
+                    if (primary) { hand[H_GH2R * SL] = gr; hand[H_GH2Z * SL] = gz; if (!CS_WN_ON_C) hand[H_GH2N * SL] = gn; }   // read by C in window 2 of the next step
                 };
-                {
-                    // Between two slabs the S wave can look at the token of the C wave it shares the SIMD with (CS_YIELD, developer knob;
-                    // measured and not shipped: the paused S wave reaches B2 late)
-                    auto yield = [&]() {
-                        if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); }
-                        if (CS_THROTTLE) __builtin_amdgcn_s_sleep(CS_THROTTLE);   // developer knob: a gap between the slabs of a shadow product
-                    };
-                    if (CS_DIAG & 112) diag_gates<NQ, (CS_DIAG & 112)>(wv, vH1, acc1);
-                    else if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : CS_DGS), decltype(yield), 0, (CS_YIELD != 0 || CS_THROTTLE != 0)>(wv, vH1, acc1, yield);
-                }
+                if (CS_SMPRIO) __builtin_amdgcn_s_setprio(CS_SMPRIO);
+                if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : 1), decltype(yield), 0, (CS_YIELD != 0)>(wv, vH1, acc1, yield);
+                if (CS_SMPRIO) __builtin_amdgcn_s_setprio(0);
                 PBW(7);
                 if (!CS_LATE_FOLD) fold1();
                 PBW(8);
-                __syncthreads();   // B2
+                __syncthreads();   // B2: x3 -> Q
                 PBW(10);
                 if (CS_LATE_FOLD) fold1();
-                if (!(CS_DIAG & 2)) {
-                    f4 xq[NQ], xp[NQ], wn = wnl[0];
+
+                // ---------------- window 3: gh2' = W_hh2 . (x3 - x2) + b_hh2 of the next step: gates r, z (the weights in this wave's registers);
+                // gate n (A operands in LDS) is the C wave's, between its fc1 publish and its fc1 look (CS_WN_ON_C) ----------------
+                {
+                    if (CS_SMPRIO) __builtin_amdgcn_s_setprio(CS_SMPRIO);
+                    if (!(CS_DIAG & 2)) {
+                        f4 xq[NQ], xp[NQ], wn = (f4){0.f, 0.f, 0.f, 0.f};
+                        if (!CS_WN_ON_C) wn = wnl[0];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
+                        for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
 #pragma unroll
-                    for (int S = 0; S < 8; ++S) {
-                        if (CS_YIELD == 2) { for (unsigned sp = 0; sp < 20000u && *tok != 0; ++sp) __builtin_amdgcn_s_sleep(1); }
-                        if (CS_THROTTLE) __builtin_amdgcn_s_sleep(CS_THROTTLE);
-                        f4 b[NQ];
+                        for (int S = 0; S < 8; ++S) {
+                            yield();
+                            f4 b[NQ];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
-                        const f4 wcur = wn;
-                        if (S < 7) {
-                            wn = wnl[(S + 1) * 64];
+                            for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
+                            const f4 wcur = wn;
+                            if (S < 7) {
+                                if (!CS_WN_ON_C) wn = wnl[(S + 1) * 64];
 #pragma unroll
-                            for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8 + S + 1) * 64]; xp[q] = vP[(q * 8 + S + 1) * 64]; }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float wr = wv[96 + 4 * S + e], wz = wv[128 + 4 * S + e];
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) {
-                                acc2[0][q] = mfma4(wr, b[q][e], acc2[0][q]);
-                                acc2[1][q] = mfma4(wz, b[q][e], acc2[1][q]);
-                                acc2[2][q] = mfma4(wcur[e], b[q][e], acc2[2][q]);
+                                for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8 + S + 1) * 64]; xp[q] = vP[(q * 8 + S + 1) * 64]; }
                             }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float wr = wv[96 + 4 * S + e], wz = wv[128 + 4 * S + e];
+#pragma unroll
+                                for (int q = 0; q < NQ; ++q) {
+                                    acc2[0][q] = mfma4(wr, b[q][e], acc2[0][q]);
+                                    acc2[1][q] = mfma4(wz, b[q][e], acc2[1][q]);
+                                    if (!CS_WN_ON_C) acc2[NG2 - 1][q] = mfma4(wcur[e], b[q][e], acc2[NG2 - 1][q]);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (CS_SMPRIO) __builtin_amdgcn_s_setprio(0);
+                    PBW(12);
+                    if (!CS_LATE_FOLD) fold2();
                 }
-                if (!CS_LATE_FOLD) fold2();
-                PBW(12);
+                PBW(13);
                 __syncthreads();   // B3
                 PBW(14);
                 if (CS_LATE_FOLD) fold2();
 
-                // ---------------- window 4: sampling noise of the next step (C reads this step's parity in window 5) ----------------
-                if (!CS_NOISE_W1 && t + 1 < bsteps) noise_step(t + 1, par ^ 1u);
-                if (CS_COND_W4 && t + 1 < bsteps) cond_step(t + 1);   // the cd slots are read in phase A of the next step only
+                // ---------------- window 4: the conditioning of the next step (the cd slots are read in phase A of the next step only; the frame
+                // constants wait for B4: C still reads this frame's c4 in this window) ----------------
+                if (CS_COND_W4 && t + 1 < bsteps) cond_step(t + 1);
                 PBW(16);
-                __syncthreads();   // B4
+                __syncthreads();   // B4: fc2 outputs -> P
                 PBW(19);
 
-                // ---------------- window 5: conditioning of the next step ----------------
-                // (MOL: in front of B4b -- behind it the C waves only sample, 800 cycles, and then waited 775 at B5 for this)
+                // ---------------- window 5: frame constants of a new frame; this wave's half of fc3 (+ its candidate of the race, RAW) ----------------
                 if (CS_COND_W4) frame_flush(); else if (t + 1 < bsteps) cond_step(t + 1);
-                if (FC3_SPLIT) {   // this wave's half of fc3 (see the C waves' window 5)
-                    const float lg1 = fc3_one_set<NQ, D3>(w3 + 8 * 64, vP, my_rq) + cst[C_B31 * SL];
-                    if (primary) lgt[rb * 32 + cls0 + 4] = lg1;
-                    if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 + 4 < NC)
+                if (FC3_SPLIT) {   // classes 8 wl + iu + 4 (see the C waves' window 5)
+                    float lg1 = 0.f;
+                    if (wg_has_fc3) lg1 = fc3_one_set<NQ, D3>(w3 + 8 * 64, vP, my_rq) + cst[C_B31 * SL];
+                    if (MODE == WRNN_MODE_MOL && primary) lgt[rb * 32 + cls0 + 4] = lg1;
+                    if (a.logits_out && primary && row_ok && t < rw.steps && (MODE != WRNN_MODE_MOL || g == 0) && cls0 + 4 < NC)
                         a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0 + 4] = lg1;
+                    if (MODE == WRNN_MODE_RAW) {
+                        float v = cls0 + 4 < NC ? lg1 + hand[(H_NZ + 2 * par + 1) * SL] : -INFINITY;
+                        int k = cls0 + 4;
+                        race_fold(v, k);
+                        if (primary && rho == 0)
+                            st_granule(mail, L::M_PR / 2u + par * L::PRG + (unsigned)rb * 256u + (unsigned)(g * 8 + wl * 2 + 1),
+                                       (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
+                    }
                 }
                 PBW(17);
-                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: C's fc3 outputs of all rows are in LDS
+                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: the fc3 outputs of all rows are in LDS
                 if (NBC < NQ) {
                     // exchange 5 for batch row wl + 4 (RAW, 8 rows per team): the C wave of this SIMD finishes row wl meanwhile.  One row per
                     // wave instead of two one after the other in the four C waves (1 130 -> ~600 cycles at the end of the serial chain).
                     const int brow = wl + 4;
                     const unsigned tg = epoch & 0x3fffffu;
-                    u4v gq;
+                    const unsigned cb = (L::M_PR / 2u + par * L::PRG + (unsigned)brow * 256u) * 8u;
+                    u4v ga, gb;
                     unsigned spins = 0;
                     for (;;) {
-                        gq = ld_pair(mrs, (unsigned)lane * 16u, (LM::G_PR + par * LM::PRG + (unsigned)brow * 128u) * 8u);
-                        if (__all((gq.y >> 10) == tg && (gq.w >> 10) == tg) || dead) break;
+                        ga = ld_pair(mrs, (unsigned)lane * 32u, cb);
+                        gb = ld_pair(mrs, (unsigned)lane * 32u, cb + 16u);
+                        if (__all((ga.y >> 10) == tg && (ga.w >> 10) == tg && (gb.y >> 10) == tg && (gb.w >> 10) == tg) || dead) break;
                         if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 28u); break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
                     float xf = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + frowS[1]] : 0.0f;
                     asm volatile("" : "+v"(xf));
-                    const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
-                    const bool pb = vb > va;   // equal scores: the lower slot = the lower class range wins
-                    const float best = pb ? vb : va;
-                    const int besti = (int)((pb ? gq.w : gq.y) & 1023u);
-                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
-                    const u64 ball = __ballot(best == mx);
-                    const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
-                    const int lab = __builtin_amdgcn_readlane(besti, src);
+                    const int lab = race_winner(ga, gb);
                     const float x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
                     if (lane == 0) {
                         xn[brow] = a.x_forced ? xf : x_new;   // (:237)

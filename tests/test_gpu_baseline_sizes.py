@@ -23,7 +23,10 @@ import torch
 from oracle import oracle as orc
 from tests.golden_util import load_case
 from tests.parity_util import (MOL_LSB, ROW_ROTATION, bound_near_ties, check_free_run_raw, check_on_gpu_trajectory_mol,
-                               check_on_gpu_trajectory_raw, label_stats, parity_report)
+                               check_on_gpu_trajectory_raw, label_stats, near_tie_truth, parity_report)
+
+# PARITY_ROWS=subset (developer sessions): the T = 401 tests check a rotating subset of the rows instead of all of them
+SUBSET = os.environ.get('PARITY_ROWS', 'all') == 'subset'
 
 pytestmark = pytest.mark.gpu
 
@@ -117,6 +120,13 @@ def _philox_q(seed, L, rows, chunk=4096):
     return q
 
 
+def _philox_q_at(seed, t, row):
+    """The 1024 Exp(1) draws of ONE (step, row) of the device's Philox stream, as the oracle is handed them."""
+    from tests.philox_ref import philox_uniform_raw_torch
+    u = philox_uniform_raw_torch(seed, int(t), 1, [int(row)], device='cuda')
+    return (-torch.log(u.to(torch.float64))).to(torch.float32).cpu().numpy()[0, 0]
+
+
 def _check_rows_raw(tag, sd, mels, lab, smp, seed, rows, group):
     """Rows `rows` of a Philox-sampled RAW batch against the oracle, `group` rows per oracle call (bounds the host copy of the
     replayed draws: L x group x 1024 floats).  Every step of every listed row is compared."""
@@ -128,6 +138,9 @@ def _check_rows_raw(tag, sd, mels, lab, smp, seed, rows, group):
         st = check_on_gpu_trajectory_raw(lab[rs].T, smp[rs].T, _forced_raw(om, mels, rs, _philox_q(seed, L, rs)))
         compared += st['compared']
         near += [(t, rs[r], d) for t, r, d in st['near_ties']]
+        for t, r, _ in st['near_ties']:   # float64 verdict on every near-tie (tests/parity_util.near_tie_truth)
+            q_t = _philox_q_at(seed, t, rs[r])
+            near_tie_truth(tag, sd, mels[rs[r]], smp[rs[r]], t, q_t, lab[rs[r], t], st['ref'], r)
     _report(tag, dict(compared=compared, near_ties=near, max_abs_other=0))
     assert compared == L * len(rows)
     return near
@@ -186,8 +199,8 @@ def test_config2_b64_injected_reference_noise_all_rows():
 
 def test_config2_b64_t401_full_size_rows():
     """configs[2] at the BASELINE size itself: 64 utterances x mel 80x401 (110 275 steps each, the bench.py workload).
-    16 rows -- two per XCD team, at positions that rotate with tests/parity_util.ROW_ROTATION so that over the rounds every
-    (team, position) pair is covered -- are checked over all their 110 275 steps."""
+    ALL 64 rows are checked over all their 110 275 steps (round 5; rounds 3-4 checked 8 / 16 rotating rows): 7 057 600 steps, the
+    oracle walking 16 rows at a time in parallel.  A near-tie, if one occurs, is re-evaluated in float64 and reported."""
     from tacotronv2_wavernn_chinese_amd import _cabi
     from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
     sd = make_state_dict(0, variant='peaky')
@@ -198,8 +211,9 @@ def test_config2_b64_t401_full_size_rows():
     res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_PHILOX, seed=seed)
     assert m.last_timing['kernel'] in (_cabi.KERNEL_BATCH, _cabi.KERNEL_BATCH_CS)
     lab, smp = res['labels'].cpu().numpy(), res['samples'].cpu().numpy()
-    rows = sorted(8 * k + (k + ROW_ROTATION + h) % 8 for k in range(8) for h in (0, 4))
-    _check_rows_raw(f'configs[2] B=64 T=401 philox, {_cabi.KERNEL_NAMES[m.last_timing["kernel"]]} kernel, rows {rows}', sd, mels, lab, smp, seed, rows, 4)
+    rows = sorted(8 * k + (k + ROW_ROTATION + h) % 8 for k in range(8) for h in (0, 4)) if SUBSET else list(range(B))
+    _check_rows_raw(f'configs[2] B=64 T=401 philox, {_cabi.KERNEL_NAMES[m.last_timing["kernel"]]} kernel, rows {rows if SUBSET else "all 64"}', sd, mels, lab, smp, seed,
+                    rows, 4 if SUBSET else 16)
     assert len({lab[i, :4000].tobytes() for i in range(B)}) == B
 
 
@@ -237,9 +251,36 @@ def test_config4_mol_b32_batch_kernel_all_rows():
 
 
 def test_config4_mol_b32_t401_full_size_rows():
-    """configs[4] at the BASELINE size: 32 utterances x mel 80x401; 8 rows (one per team, the position inside the team's row quad
-    rotating with tests/parity_util.ROW_ROTATION) over all 110 275 steps."""
-    _mol_case(32, 401, sorted(4 * k + (k + ROW_ROTATION) % 4 for k in range(8)), 'configs[4] MOL B=32 T=401')
+    """configs[4] at the BASELINE size: 32 utterances x mel 80x401; ALL 32 rows over all 110 275 steps (round 5; before: 8 rotating rows)."""
+    _mol_case(32, 401, sorted(4 * k + (k + ROW_ROTATION) % 4 for k in range(8)) if SUBSET else list(range(32)), 'configs[4] MOL B=32 T=401')
+
+
+def test_mol_eight_rows_per_team():
+    """MOL at 8 rows per XCD team (B = 40 -> 5 rows per batch -> the two-quad instantiation loop_batch_cs_kernel<MOL, 2>; round-4 advisor: every MOL
+    parity case had B <= 32, i.e. one quad): all 40 rows, every step, against the oracle -- and the same instantiation teacher-forced with its
+    fc3 outputs (forward()'s path: x_forced + logits_out) against the 4-rows-per-team run of the same batch."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
+    _mol_case(40, 21, list(range(40)), 'MOL B=40 T=21 (8 rows per team)')
+    sd = make_state_dict(0, mode='MOL', variant='default', bits=9)
+    B, T = 12, 6
+    L = T * 275
+    mels = make_mels(31, B, T)
+    rng = np.random.Generator(np.random.PCG64(5))
+    xf = rng.uniform(-1.0, 1.0, size=(L, B)).astype(np.float32)
+    u_mix = rng.uniform(1e-5, 1.0 - 1e-5, size=(L, B, 10)).astype(np.float32)   # the fc3 outputs of a forced trajectory do not depend on the noise
+    u_log = rng.uniform(1e-5, 1.0 - 1e-5, size=(L, B)).astype(np.float32)
+    m = _model(sd, mode='MOL', bits=9, kernel='batch_cs')
+    kw = dict(noise_mode=_cabi.NOISE_INJECTED, noise1=u_mix, noise2=u_log, x_forced=xf, want_logits=True)
+    r8 = m.generate_raw(mels, False, 11000, 550, batch_rows=8, **kw)
+    l8 = r8['logits'].cpu().numpy()
+    r4 = m.generate_raw(mels, False, 11000, 550, batch_rows=4, **kw)
+    l4 = r4['logits'].cpu().numpy()
+    assert np.isfinite(l8).all() and np.abs(l8 - l4).max() <= 2e-5 * max(1.0, float(np.abs(l4).max()))
+    om = orc.OracleModel(sd, mode='MOL', bits=9, fast=True)
+    cm, ca = om.conditioning(mels)
+    ref = om.loop(cm, ca, 0, u_mix, u_log, x_forced=xf, want_logits=True)
+    assert np.abs(l8 - ref['logits']).max() <= 2e-5 * max(1.0, float(np.abs(ref['logits']).max()))
 
 
 @pytest.mark.parametrize('kernel', ['team2', 'batch', 'batch_cs'])

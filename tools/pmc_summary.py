@@ -2,6 +2,7 @@
 --kernel-trace run and per-kernel counter sums of --pmc runs.
 
     python tools/pmc_summary.py <dir> [kernel-name-substring ...]
+    python tools/pmc_summary.py <dir> --json profiles/rNN_pmc.json     # + the per-launch counter numbers bench.py attaches to its roofline objects
 
 Walks <dir> for *_results.db; prints, per database, the top kernels by total time (calls, average, total) and, where
 counters were collected, the sum of every counter over all dispatches of each kernel whose name contains one of the
@@ -15,8 +16,68 @@ import sqlite3
 import sys
 
 
+def write_json(root: str, out: str) -> None:
+    """profiles/rNN_pmc.json for bench.py: per BASELINE config (the directories <what>_c<N> of tools/profile_round.sh) the dominant loop kernel's HBM
+    bytes and MFMA-busy cycles PER LAUNCH and its kernel-trace average, stamped with the commit and the hash of the kernel sources it ran on."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench
+    cfgs = {}
+    for c in (1, 2, 4):
+        rec = {}
+        for what in ('kt', 'fetch', 'write', 'inst', 'sq'):
+            dbs = glob.glob(os.path.join(root, f'{what}_c{c}', '**', '*_results.db'), recursive=True)
+            if not dbs:
+                continue
+            con = sqlite3.connect(dbs[0])
+            try:
+                if what == 'kt':
+                    r = con.execute("select name, count(*), avg(duration) from kernels where name like '%loop_%' group by name order by sum(duration) desc limit 1").fetchone()
+                    if r:
+                        rec.update(kernel=r[0], kt_calls=r[1], kt_avg_ms=r[2] / 1e6)
+                else:
+                    rows = con.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection "
+                                       "where kernel_name like '%loop_%' group by kernel_name, counter_name").fetchall()
+                    top = max({k for k, _, _, _ in rows}, key=lambda k: sum(v for kk, _, v, _ in rows if kk == k), default=None) if what != 'fetch' else None
+                    for kname, cname, val, nd in rows:
+                        if top is not None and kname != top:
+                            continue
+                        rec.setdefault('kernel', kname)
+                        if cname == 'FETCH_SIZE':
+                            rec['fetch_bytes_per_launch'] = int(val * 2 * 1024 / nd)        # KB x 2: the gfx950 correction of MI355X_MICROARCH.md
+                        elif cname == 'WRITE_SIZE':
+                            rec['write_bytes_per_launch'] = int(val * 1024 / nd)
+                        elif cname == 'SQ_VALU_MFMA_BUSY_CYCLES':
+                            rec['mfma_busy_cycles_per_launch'] = int(val / nd)
+                        elif cname == 'SQ_INSTS_MFMA':
+                            rec['insts_mfma_per_launch'] = int(val / nd)
+                        elif cname in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE'):
+                            rec[cname] = int(val / nd)
+            except sqlite3.Error:
+                pass
+            con.close()
+        rec.setdefault('fetch_bytes_per_launch', 0)
+        rec.setdefault('write_bytes_per_launch', 0)
+        rec.setdefault('mfma_busy_cycles_per_launch', 0)
+        if 'kernel' in rec:
+            cfgs[str(c)] = rec
+    commit = os.environ.get('COMMIT', '')
+    if not commit:
+        try:
+            commit = subprocess.check_output(['git', 'log', '-1', '--format=%h'], text=True, stderr=subprocess.DEVNULL).strip()
+        except (OSError, subprocess.CalledProcessError):
+            commit = 'unknown'
+    with open(out, 'w') as f:
+        json.dump(dict(commit=commit, csrc_sha=bench.csrc_sha(), tool='tools/profile_round.sh + tools/pmc_summary.py --json', configs=cfgs), f, indent=1)
+    print(f'wrote {out}: commit {commit}, kernel sources {bench.csrc_sha()}, configs {sorted(cfgs)}')
+
+
 def main() -> int:
     root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out'
+    if '--json' in sys.argv:
+        write_json(root, sys.argv[sys.argv.index('--json') + 1])
+        return 0
     pats = sys.argv[2:] or ['loop_']
     for db in sorted(glob.glob(os.path.join(root, '**', '*_results.db'), recursive=True)):
         con = sqlite3.connect(db)

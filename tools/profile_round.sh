@@ -1,5 +1,5 @@
 #!/bin/bash
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'TAG=r03 bash tools/profile_round.sh'   (the summaries go to profiles/<TAG>_*.txt)
+#   /usr/local/graft/bin/gpurun --timeout 900 -- "COMMIT=$(git log -1 --format=%h) TAG=r05 bash tools/profile_round.sh"   (copy pmc_summary.txt -> profiles/<TAG>_rocprofv3_summary.txt, pmc.json -> profiles/<TAG>_pmc.json)
 # GPU box: rocprofv3 kernel-trace stats of the bench command for configs 1, 2, 4 and PMC passes (HBM traffic; wave-cycle
 # split, LDS conflicts) for the dominant loop kernels.  Counters are collected in their own runs (no tracing).
 mkdir -p gpurun_out/prof_${TAG:-rXX}
@@ -17,3 +17,5 @@ done
 cd $R
 for f in $(find gpurun_out/prof_${TAG:-rXX} -name "*kernel_stats*csv"); do echo "== $f"; head -8 $f; done
 python tools/pmc_summary.py gpurun_out/prof_${TAG:-rXX} > gpurun_out/prof_${TAG:-rXX}/pmc_summary.txt 2>&1; cat gpurun_out/prof_${TAG:-rXX}/pmc_summary.txt
+# the per-launch counter numbers bench.py attaches to its roofline objects, stamped with COMMIT (pass it: the GPU box has no .git) and the kernel-source hash
+python tools/pmc_summary.py gpurun_out/prof_${TAG:-rXX} --json gpurun_out/prof_${TAG:-rXX}/pmc.json
