@@ -33,11 +33,12 @@
 //     {tag, x2} look -- and writes both P and H1.  The S waves' own 32 KB look (2 280 cycles at R = 8, stretched by the C waves' phase-B
 //     MFMAs), their LDS meeting point and its flags are gone; W_hh1.h1' starts at B1 and ends before the C waves' x3 look goes out
 //     (profiles/r04_batch_cs_experiments.txt: a look beside a multiplying neighbour wave returns only when the neighbour's MFMA stream ends).
-//   * who empties a word: its producer.  Step e uses parity p = e & 1.  When a workgroup has gathered the pairs of step e from all 32
-//     workgroups, every workgroup has finished every read of step e - 1 (a pair is published after the previous step's last gather), so
-//     the producer stores CS_EMPTY into its own words of parity 1 - p -- together with its x3 publish (one store round trip for both).
-//     They must have reached the L2 before anybody polls parity 1 - p again (step e + 1): the producer waits for its stores
-//     (s_waitcnt vmcnt(0), free by then) before it publishes fc1 of step e, and nobody enters step e + 1 without having gathered that.
+//   * who empties a word: its producer's workgroup.  Step e uses parity p = e & 1.  When a workgroup's C waves have gathered x2 of step e
+//     from all 32 workgroups (barrier B1), every workgroup has finished every read of step e - 1 (x2 is published after the previous
+//     step's last gather), so the S lane of the same (unit, row) stores CS_EMPTY into the workgroup's words of parity 1 - p right behind B1
+//     -- off the serial chain.  The stores must have reached the L2 before anybody polls parity 1 - p again (step e + 1): the S wave waits
+//     for them (s_waitcnt vmcnt(0), free by then) in front of B3, the C waves publish fc2 of step e behind B3, and nobody enters step
+//     e + 1 without having gathered that.  The next store to such a word is the C lane's publish of step e + 1: behind B3..B5 as well.
 //     A pass (batch) boundary changes nothing: the epoch keeps counting, the first gather of the next batch empties the last step's words.
 //   * api.hip fills the mailbox with 0xff bytes before the launch.  A model that produces the CS_EMPTY pattern itself (only possible with
 //     such NaN payloads in its inputs) runs into the bounded spin and reports WRNN_ERR_TIMEOUT -- never a silently wrong sample.
@@ -73,7 +74,8 @@
 #endif
 #ifndef CS_YIELD
 #define CS_YIELD 0       // an S wave issues MFMAs of a shadow product only while the C wave of its SIMD multiplies or waits for a sentinel (token in LDS, looked
-                         // at in front of every slab): 1 = not beside C's fold / gates / publish, 2 = not beside C's data look + LDS write either
+                         // at in front of every slab): 1 = not beside C's fold / gates / publish, 2 = not beside C's data look + LDS write either, 3 = W_hh1 not before C's x3 publish
+                         // (the round-4 timing of that product without the S waves' own look)
 #endif
 #ifndef CS_WN_ON_C
 #define CS_WN_ON_C 1     // gate n of W_hh2.(x3 - x2) (A operands in LDS, 64 MFMAs at 8 rows) by the C wave between its fc1 publish and the fc1 look: the
@@ -139,7 +141,7 @@ struct LayCS {
     static constexpr unsigned M_XH = 0;                                  // {x2, h1'} pairs: 2 parities x 2 RGD
     static constexpr unsigned M_X3 = 4 * RGD, M_F1 = 6 * RGD, M_F2 = 8 * RGD;   // 2 parities x RGD each
     static constexpr unsigned M_PR = 10 * RGD;                           // race candidates: 2 parities x PRG granules of 8 bytes
-    static constexpr unsigned PRG = (unsigned)R * 256u;                  // [row][32 workgroups][8 waves]
+    static constexpr unsigned PRG = (unsigned)R * 256u;                  // [row][32 workgroups][8 waves] (CS_FC3_SPLIT_RAW; else [row][32][4 C waves], half of it used)
     static constexpr unsigned MAIL_WORDS = M_PR + 2 * 2 * PRG;
     static_assert(MAIL_WORDS <= 2 * WRNN_BATCH_MAIL_GRANULES, "mailbox budget");
     static constexpr int NMP = R;                   // 16-byte loads per thread (256 threads) of a pair vector
@@ -270,14 +272,18 @@ __device__ __forceinline__ void race_fold(float &v, int &k) {
         v = tb ? vb : va; k = tb ? kb : ka;
     }
 }
-// ... and the winner among a row's 256 candidates {tag | class, score}: lane l holds slots 4 l .. 4 l + 3 (two 16-byte loads); slots are in class
-// order (workgroup, wave pair, C before S), so "the first of equal scores" is the lowest class, as torch's argmax of p / q picks it
+// ... and the winner among a row's candidates {tag | class, score}: lane l holds slots 2 l, 2 l + 1 (one 16-byte load: 128 candidates, one per C wave) or
+// 4 l .. 4 l + 3 (two loads: 256, one per wave, CS_FC3_SPLIT_RAW); slots are in class order (workgroup, wave pair, C before S), so "the first of equal
+// scores" is the lowest class, as torch's argmax of p / q picks it
+template <bool TWO>
 __device__ __forceinline__ int race_winner(const u4v &ga, const u4v &gb) {
     float best = __uint_as_float(ga.x);
     unsigned bk = ga.y;
     { const float v = __uint_as_float(ga.z); if (v > best) { best = v; bk = ga.w; } }
-    { const float v = __uint_as_float(gb.x); if (v > best) { best = v; bk = gb.y; } }
-    { const float v = __uint_as_float(gb.z); if (v > best) { best = v; bk = gb.w; } }
+    if (TWO) {
+        { const float v = __uint_as_float(gb.x); if (v > best) { best = v; bk = gb.y; } }
+        { const float v = __uint_as_float(gb.z); if (v > best) { best = v; bk = gb.w; } }
+    }
     const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
     const u64 ball = __ballot(best == mx);
     const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
@@ -525,7 +531,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                     for (int m = 0; m < NMW; ++m) gd4[0 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
-                tok_set(1);
+                tok_set(CS_YIELD == 3 ? 0 : 1);
                 PBW(2);
                 __syncthreads();   // B1
                 PBW(3);
@@ -538,7 +544,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                     mfma_gates<NQ, 3, false, DG>(wv, vP, acc, NoMid());
-                    tok_set(0);   // the fold and the gates are a dependent VALU chain: beside an MFMA stream they take three times as long (session 1)
+                    if (CS_YIELD != 3) tok_set(0);   // the fold and the gates are a dependent VALU chain: beside an MFMA stream they take three times as long (session 1)
                     PBW(4);
                     float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -552,17 +558,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     const float ng = tanh_fast((tn + hand[H_C2N * SL]) + rg * (CS_WN_ON_C ? gh2n : hand[H_GH2N * SL]));
                     h2 = (1.0f - zg) * ng + zg * h2;
                     const float x3 = x2own + h2;
-                    if (primary) {
-                        st_word(mailw, L::M_X3 + par * L::RGD + mb_own, __float_as_uint(x3));
-                        // everybody has published the pairs of this step, i.e. finished every read of the previous one: its words (other parity)
-                        // are emptied by their producer, in the same store round trip as the publish (see the protocol at the top)
-                        const unsigned op = par ^ 1u;
-                        if (CS_PAIR) st_pair(mailw, L::M_XH + op * 2u * L::RGD + 2u * mb_own, CS_EMPTY, CS_EMPTY);
-                        else { st_word(mailw, L::M_XH + op * 2u * L::RGD + mb_own, CS_EMPTY); st_word(mailw, L::M_XH + op * 2u * L::RGD + L::RGD + mb_own, CS_EMPTY); }
-                        st_word(mailw, L::M_X3 + op * L::RGD + mb_own, CS_EMPTY);
-                        st_word(mailw, L::M_F1 + op * L::RGD + mb_own, CS_EMPTY);
-                        st_word(mailw, L::M_F2 + op * L::RGD + mb_own, CS_EMPTY);
-                    }
+                    if (primary) st_word(mailw, L::M_X3 + par * L::RGD + mb_own, __float_as_uint(x3));
                     tok_set(1);   // from here the wave waits for a sentinel
                 }
                 PBW(6);
@@ -587,16 +583,13 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 {
                     f4 sum[NQ];
                     mfma_single<NQ, (NQ == 1 ? 4 : 2), false, DS>(wv + 96, vQ, sum);
-                    tok_set(0);
+                    if (CS_YIELD != 3) tok_set(0);
                     float s = 0.f;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const float f = fold_kp(sum[q]);
                         if (q == 0 || my_rq == q) s = f;
                     }
-                    // the CS_EMPTY stores of window 2 have reached the L2 before anybody can poll their parity again (protocol, top of the file): the
-                    // x3 look behind them is long back, the wait is free
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (primary) st_word(mailw, L::M_F1 + par * L::RGD + mb_own, __float_as_uint(fmaxf(s + hand[H_C3 * SL], 0.0f)));
                     tok_set(1);
                 }
@@ -749,9 +742,8 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         }
                         race_fold(v, k);
                         if (primary && rho == 0) {
-                            const unsigned slot = L::M_PR / 2u + par * L::PRG + (unsigned)rb * 256u + (unsigned)(g * 8 + wl * 2);
+                            const unsigned slot = L::M_PR / 2u + par * L::PRG + (unsigned)rb * 256u + (FC3_SPLIT ? (unsigned)(g * 8 + wl * 2) : (unsigned)(g * 4 + wl));
                             st_granule(mail, slot, (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
-                            if (!FC3_SPLIT) st_granule(mail, slot + 1u, (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));   // the S wave's slot
                         }
                     } else {
                         // MOL: the wave's 8 fc3 outputs of every batch row -> LDS; wave w samples batch rows w, w + 4 behind the barrier
@@ -768,8 +760,8 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                         for (int i = 0; i < NBC; ++i) {
                             const unsigned cb = (L::M_PR / 2u + par * L::PRG + (unsigned)(wl + 4 * i) * 256u) * 8u;
-                            gqa[i][0] = ld_pair(mrs, (unsigned)lane * 32u, cb);
-                            gqa[i][1] = ld_pair(mrs, (unsigned)lane * 32u, cb + 16u);
+                            gqa[i][0] = ld_pair(mrs, (unsigned)lane * (FC3_SPLIT ? 32u : 16u), cb);
+                            gqa[i][1] = FC3_SPLIT ? ld_pair(mrs, (unsigned)lane * 32u, cb + 16u) : gqa[i][0];
                         }
                         bool ok = true;
 #pragma unroll
@@ -797,7 +789,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     float x_new;
                     int lab;
                     if (MODE == WRNN_MODE_RAW) {
-                        lab = race_winner(gqa[bi][0], gqa[bi][1]);
+                        lab = race_winner<FC3_SPLIT>(gqa[bi][0], gqa[bi][1]);
                         x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
                     } else {
                         // sample_from_discretized_mix_logistic (distribution.py:87-123) for batch row `brow`
@@ -947,11 +939,21 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 PBW(2);
                 __syncthreads();   // B1: the C waves have written x2 -> P and h1' -> H1
                 PBW(3);
-
-                // ---------------- window 2: gh1' = W_hh1 . h1' + b_hh1 of the next step, from B1 on, beside the C waves' phase-B MFMAs (two waves
-                // keep the SIMD's matrix pipe busier than one: 4 instead of 8 cycles per MFMA, bench_micro/mfma4_probe): the product is over long
-                // before the C waves' x3 look goes out -- a look beside a multiplying neighbour comes back when the neighbour's MFMA stream ends
-                // (profiles/r04_batch_cs_experiments.txt, last section).  The fold follows at once: the S waves wait at B2 anyway. ----------------
+                // The C waves have gathered this step's x2 from all 32 workgroups: everybody has finished every read of the PREVIOUS step.  Its words (other
+                // parity) are emptied by their producer's S lane -- same lane = same (unit, row) = same word as the C lane that published it -- off the
+                // serial chain (session 2: issued by the C waves with their x3 publish, the five stores cost the x3 exchange ~550 cycles; session 3: in
+                // front of the S waves' own h1' look they cost THAT look ~800 cycles -- a wave's loads are counted behind its stores -- so behind it).
+                auto empty_previous = [&]() {
+                    if (primary) {
+                        const unsigned op = par ^ 1u;
+                        if (CS_PAIR) st_pair(mailw, L::M_XH + op * 2u * L::RGD + 2u * mb_own, CS_EMPTY, CS_EMPTY);
+                        else { st_word(mailw, L::M_XH + op * 2u * L::RGD + mb_own, CS_EMPTY); st_word(mailw, L::M_XH + op * 2u * L::RGD + L::RGD + mb_own, CS_EMPTY); }
+                        st_word(mailw, L::M_X3 + op * L::RGD + mb_own, CS_EMPTY);
+                        st_word(mailw, L::M_F1 + op * L::RGD + mb_own, CS_EMPTY);
+                        st_word(mailw, L::M_F2 + op * L::RGD + mb_own, CS_EMPTY);
+                    }
+                };
+                if (CS_PAIR) empty_previous();
                 // an S wave looks at the token of the C wave it shares the SIMD with in front of every slab (CS_YIELD)
                 auto yield = [&]() {
                     if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok == 0; ++sp) __builtin_amdgcn_s_sleep(1); }
@@ -978,6 +980,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     asm volatile("" ::: "memory");
                     PBW(6);
                     __builtin_amdgcn_s_setprio(0);
+                    empty_previous();
                 }
                 constexpr int NG2 = CS_WN_ON_C ? 2 : 3;
                 f4 acc1[3][NQ], acc2[NG2][NQ];
@@ -1056,6 +1059,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     PBW(12);
                     if (!CS_LATE_FOLD) fold2();
                 }
+                // the CS_EMPTY stores of window 2 must have reached the L2 before anybody polls their parity again (next step).  They have, thousands of
+                // cycles ago -- made certain HERE: behind B3 the C waves publish fc2, and nobody enters the next step without having gathered that.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PBW(13);
                 __syncthreads();   // B3
                 PBW(14);
@@ -1096,15 +1102,15 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     u4v ga, gb;
                     unsigned spins = 0;
                     for (;;) {
-                        ga = ld_pair(mrs, (unsigned)lane * 32u, cb);
-                        gb = ld_pair(mrs, (unsigned)lane * 32u, cb + 16u);
+                        ga = ld_pair(mrs, (unsigned)lane * (FC3_SPLIT ? 32u : 16u), cb);
+                        gb = FC3_SPLIT ? ld_pair(mrs, (unsigned)lane * 32u, cb + 16u) : ga;
                         if (__all((ga.y >> 10) == tg && (ga.w >> 10) == tg && (gb.y >> 10) == tg && (gb.w >> 10) == tg) || dead) break;
                         if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 28u); break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
                     float xf = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + frowS[1]] : 0.0f;
                     asm volatile("" : "+v"(xf));
-                    const int lab = race_winner(ga, gb);
+                    const int lab = race_winner<FC3_SPLIT>(ga, gb);
                     const float x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
                     if (lane == 0) {
                         xn[brow] = a.x_forced ? xf : x_new;   // (:237)
