@@ -604,8 +604,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
             // team kernels of one device run one after the other, whatever handle / stream launches them (wavernn_amd.h); the
             // mailbox reset belongs inside the gate: the handle's previous team kernel may still be reading it
             HIP_TRY(h, wrnn_team_gate_enter(h->cfg.device, s));
-            // (BATCH_CS publishes untagged words: an empty mailbox word is 0xffffffff there, see loop_batch_cs.hip; BATCH: tag 0 = no step)
-            hipError_t le = hipMemsetAsync(h->mail, cs ? 0xff : 0, mail_bytes, s);
+            hipError_t le = hipMemsetAsync(h->mail, 0, mail_bytes, s);
             if (le == hipSuccess) le = hipMemsetAsync(h->ctl, 0, 128, s);
             if (le == hipSuccess) le = cs ? wrnn_launch_loop_batch_cs(ba, s) : wrnn_launch_loop_batch(ba, s);
             const hipError_t ge = wrnn_team_gate_leave(h->cfg.device, s);

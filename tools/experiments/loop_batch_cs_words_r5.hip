@@ -7,46 +7,85 @@
 // wave cannot saturate the matrix pipe anyway (8.1 cycles per 4x4x1 MFMA per wave, 4.07 per SIMD with two waves).  Here a SIMD
 // holds two waves of 256 registers with different jobs, as in loop_team2.hip:
 //   waves 0-3 "C" (critical): W_ih2 (96) + fc1 (32) + fc2 (32) weights in VGPRs, the fc3 slice in LDS: phase A (I + GRU1),
-//                             phase B (GRU2), fc1, fc2, fc3 + the race; the four gathers of the serial chain (x2, x3, fc1, fc2)
-//                             and the winners.  Nothing else: between a publish and its gather a C wave only polls.
-//   waves 4-7 "S" (shadow):   W_hh1 (96) + W_hh2 gates r,z (64) in VGPRs, gate n in LDS: the h1' gather (off the serial chain
-//                             now: C waits for x2 only), gh1' = W_hh1.h1', gh2' = W_hh2.(x3 - x2), the sampling noise and the
-//                             conditioning of the NEXT step.  Results go to the C wave of the same SIMD -- same lane = same
-//                             (unit, batch row) -- through small LDS slots, separated by the step's 5 workgroup barriers.
+//                             phase B (GRU2), fc1, fc2, half of fc3 + the race; the four gathers of the serial chain and the winners.
+//   waves 4-7 "S" (shadow):   W_hh1 (96) + W_hh2 gates r,z (64) in VGPRs: gh1' = W_hh1.h1', gh2' = W_hh2.(x3 - x2), the sampling
+//                             noise, the conditioning of the NEXT step, the other half of fc3.  Results go to the C wave of the same
+//                             SIMD -- same lane = same (unit, batch row) -- through small LDS slots, separated by the step's 5
+//                             workgroup barriers.  An S wave never looks at the mailbox (round 5).
 // No AGPR parking: hipcc splits a 256-register wave 128 : 128 between VGPRs and AGPRs as soon as a kernel touches an AGPR, so this
 // file is compiled with -mllvm -amdgpu-mfma-vgpr-form (MFMA results in VGPRs; see the Makefile) and all 160 weights are plain floats.
 //
-// Team, residency, mailbox regions, granule protocol, thread <-> (unit, row) map, B-operand order in LDS, the K-phase fold and
-// the software-pipelined MFMA loops are those of loop_batch.hip (batch_common.h).  Per step: 5 exchanges, 5 barriers (all 8 waves).
-//   window 1: C phase A, publish x2 | h1', gather x2 -> P          S gather h1' -> H1
-//   window 2: C phase B (W_ih2.x2), publish x3, gather -> Q         S W_hh1.h1' -> gh1 slots
-//   window 3: C fc1, publish, gather -> H1                          S W_hh2.(Q - P) -> gh2 slots
-//   window 4: C fc2, publish, gather -> P                           S noise of step t+1 -> nz slots (other parity)
-//   window 5: C fc3 + race, publish, candidates, winners -> xn      S conditioning of step t+1 -> cd / frame-constant slots
+// Team, residency, thread <-> (unit, row) map, B-operand order in LDS, the K-phase fold and the software-pipelined MFMA loops are those
+// of loop_batch.hip (batch_common.h).  Per step: 5 exchanges (RAW; MOL 4), 5 barriers (all 8 waves):
+//   window 1: C phase A, publish {x2, h1'}, gather -> P and H1                         S noise of this step -> nz slots
+//   window 2: C phase B (W_ih2.x2), publish x3, gather -> Q                            S W_hh1.h1' -> gh1 slots (starts AT B1, beside phase B)
+//   window 3: C fc1, publish, gate n of W_hh2.(Q - P) while the data travels, gather -> H1      S W_hh2 r,z.(Q - P) -> gh2 slots
+//   window 4: C fc2, publish, gather -> P                                              S conditioning of step t+1 -> cd slots
+//   window 5: C / S half of fc3 each (+ race, RAW), publish, candidates, winners -> xn         S frame constants; RAW 8 rows: the winner of row wl + 4
+//
+// THE EXCHANGE PROTOCOL (round 5; rounds 2-4 published 8-byte {tag = step, value} granules and the S waves gathered h1' themselves):
+//   * a published vector is R x 512 plain 4-byte WORDS in the order [rq][wl][S][iu][j][e] (every 2 KB holds words of all 32 producers;
+//     a 16-byte load returns the four e of one (rq, S, kp, j) = one ds_write_b128 in B-operand order).  An empty mailbox word holds
+//     CS_EMPTY = 0xffffffff -- a NaN bit pattern no fp32 operation of this kernel produces (the hardware's NaN is 0x7fc00000) -- so THE
+//     DATA IS THE FLAG without a tag: half the bytes of a look (the tags were half of every look: 32 KB per workgroup and exchange at
+//     8 rows through a 64 B/clk port; round-4 diagnostic: a look of half the bytes is worth +4.7 % / +2.2 %).
+//   * x2 and h1' of a (unit, row) travel as ONE 8-byte pair (one store): the C waves' x2 look brings h1' with it -- the bytes of the old
+//     {tag, x2} look -- and writes both P and H1.  The S waves' own 32 KB look (2 280 cycles at R = 8, stretched by the C waves' phase-B
+//     MFMAs), their LDS meeting point and its flags are gone; W_hh1.h1' starts at B1 and ends before the C waves' x3 look goes out
+//     (profiles/r04_batch_cs_experiments.txt: a look beside a multiplying neighbour wave returns only when the neighbour's MFMA stream ends).
+//   * who empties a word: its producer's workgroup.  Step e uses parity p = e & 1.  When a workgroup's C waves have gathered x2 of step e
+//     from all 32 workgroups (barrier B1), every workgroup has finished every read of step e - 1 (x2 is published after the previous
+//     step's last gather), so the S lane of the same (unit, row) stores CS_EMPTY into the workgroup's words of parity 1 - p right behind B1
+//     -- off the serial chain.  The stores must have reached the L2 before anybody polls parity 1 - p again (step e + 1): the S wave waits
+//     for them (s_waitcnt vmcnt(0), free by then) in front of B3, the C waves publish fc2 of step e behind B3, and nobody enters step
+//     e + 1 without having gathered that.  The next store to such a word is the C lane's publish of step e + 1: behind B3..B5 as well.
+//     A pass (batch) boundary changes nothing: the epoch keeps counting, the first gather of the next batch empties the last step's words.
+//   * api.hip fills the mailbox with 0xff bytes before the launch.  A model that produces the CS_EMPTY pattern itself (only possible with
+//     such NaN payloads in its inputs) runs into the bounded spin and reports WRNN_ERR_TIMEOUT -- never a silently wrong sample.
+//   * the race candidates (RAW) keep {tag | class, score} granules: one per wave, row and step.
 #include "batch_common.h"
 
 #define CS_THREADS 512
 // Developer knobs (tools/build_variant.sh NAME loop_batch_cs -DCS_...).  What round 4 measured and rejected -- slice rotation, a throttled shadow product,
 // every polling variant except "sentinel slice first, then everything", yielding shadow waves, a v_min3 tag check, the wrong-result timing diagnostics of
-// the shadow products' operands -- is recorded in profiles/r04_batch_cs_experiments.txt and no longer lives in this file.  Round 5 rebuilt the exchange
-// (untagged 4-byte words with an "empty" bit pattern as the flag, {x2, h1'} as one 8-byte pair so that the S waves never look, W_hh1 from B1 on, gate n of
-// W_hh2 on the C waves, RAW fc3 split between the waves of a SIMD, shadow waves yielding through an LDS token): parity-green and 9-19 % SLOWER in every
-// combination (profiles/r05_batch_cs_experiments.txt; the kernel is kept as tools/experiments/loop_batch_cs_words_r5.hip).  The two waves of a SIMD share ONE
-// matrix pipe and ONE VALU issue port: a shadow MFMA is free only beside a memory wait of the critical wave, which is where this schedule has them.
+// the shadow products' operands -- is recorded in profiles/r04_batch_cs_experiments.txt and no longer lives in this file.
 #ifndef CS_PRIO
 #define CS_PRIO 1        // the C waves run at s_setprio 3: the two waves of a SIMD compete for issue slots, the serial chain goes first
 #endif
 #ifndef CS_SPLIT_WIN
-#define CS_SPLIT_WIN 1   // RAW, 8 rows per team: the winner of batch row wl + 4 is reduced by the S wave (window 5, behind its conditioning work)
-#endif
-#ifndef CS_SPRIO
-#define CS_SPRIO 1       // the S waves' h1' gather + meeting point run at the C waves' priority (+1 % at R = 4, nothing at R = 8)
+#define CS_SPLIT_WIN 1   // RAW, 8 rows per team: the winner of batch row wl + 4 is reduced by the S wave (window 5)
 #endif
 #ifndef CS_FC3_SPLIT
-#define CS_FC3_SPLIT 1   // MOL: fc3 shared between the C and the S wave of a SIMD
+#define CS_FC3_SPLIT 1   // MOL: fc3 shared between the C and the S wave of a SIMD (each wave 4 of the SIMD's 8 rows)
+#endif
+#ifndef CS_FC3_SPLIT_RAW
+#define CS_FC3_SPLIT_RAW 0   // the same for RAW (round 5, session 1: the S waves' half ends later than the C waves', the candidates wait doubles: -2 %)
+#endif
+#ifndef CS_PAIR
+#define CS_PAIR 1        // 1: x2 and h1' travel as one 8-byte pair, the C waves' look writes P and H1, the S waves never look;  0: two word vectors, the S waves
+                         // gather h1' themselves behind B1 and meet through LDS flags (the round-4 schedule on the round-5 protocol)
+#endif
+#ifndef CS_LATE_FOLD
+#define CS_LATE_FOLD (!CS_PAIR)   // the fold of a shadow product runs behind the barrier that ends its window (round 4: with their own h1' look in window 2 the S
+                                  // waves were the last at B2 / B3); with CS_PAIR they have ~3 000 cycles of slack there and fold at once
+#endif
+#ifndef CS_SMPRIO
+#define CS_SMPRIO 0      // s_setprio of an S wave while it issues the MFMAs of a shadow product (0 = stays below the C wave's 3)
+#endif
+#ifndef CS_YIELD
+#define CS_YIELD 0       // an S wave issues MFMAs of a shadow product only while the C wave of its SIMD multiplies or waits for a sentinel (token in LDS, looked
+                         // at in front of every slab): 1 = not beside C's fold / gates / publish, 2 = not beside C's data look + LDS write either, 3 = W_hh1 not before C's x3 publish
+                         // (the round-4 timing of that product without the S waves' own look)
+#endif
+#ifndef CS_WN_ON_C
+#define CS_WN_ON_C 1     // gate n of W_hh2.(x3 - x2) (A operands in LDS, 64 MFMAs at 8 rows) by the C wave between its fc1 publish and the fc1 look: the
+                         // data needs >= 600 cycles to arrive anyway, and the S waves' product (what the fc1 look waits for) shrinks by a third
+#endif
+#ifndef CS_COND_W4_RAW
+#define CS_COND_W4_RAW 0
 #endif
 #ifndef CS_COND_W4
-#define CS_COND_W4 (MODE == WRNN_MODE_MOL)   // MOL: the conditioning of the next step in window 4 (in window 5 the C waves waited for it at B4b: 780 cycles)
+#define CS_COND_W4 (MODE == WRNN_MODE_MOL || CS_COND_W4_RAW)   // the conditioning of the next step in window 4 (MOL: in window 5 the C waves waited for it at B4b)
 #endif
 #ifndef CS_PROF_SPLIT
 #define CS_PROF_SPLIT 0  // instrumented build: the C waves' exchanges are reported in two parts (sentinel wait: markers 17 / 7 / 12 / 16, the rest under the usual marker)
@@ -67,17 +106,15 @@
 #define CS_DIAG 0        // TIMING DIAGNOSTIC ONLY (wrong results): bit 0 = the S waves skip the W_hh1 MFMAs, bit 1 = the W_hh2 MFMAs
 #endif
 #ifndef CS_EARLY_LOOK
-#define CS_EARLY_LOOK 8  // the full look goes out once this many of the sentinel slice's 64 lanes carry the tag (0 = all of them)
-#endif
-#ifndef CS_FLAG_POLL_SLEEP
-#define CS_FLAG_POLL_SLEEP 1   // s_sleep units between two looks at the S waves' LDS meeting flags (0 = a tight ds_read loop at the C waves' priority beside their
-                               // phase-B MFMAs: -3.5 % / -4.5 %, round 5 session 5)
+#define CS_EARLY_LOOK 8  // the full look goes out once this many of the sentinel slice's 64 lanes hold data (0 = all of them)
 #endif
 #ifndef CS_MAX_NQ
 #define CS_MAX_NQ 2      // row quads per team this file is built for
 #endif
 
 namespace {
+
+constexpr unsigned CS_EMPTY = 0xffffffffu;   // a mailbox word nobody has published yet (see the protocol above)
 
 template <int NQ>
 struct LayCS {
@@ -93,38 +130,80 @@ struct LayCS {
     static constexpr int L_Q = L_P + VEC;           // x3
     static constexpr int L_H1 = L_Q + VEC;          // h1', later fc1 outputs
     static constexpr int L_XN = L_H1 + VEC;
-    static constexpr int L_LG = L_H1;               // [R][32] MOL: the 30 fc3 outputs of every batch row, in window 5 (H1 is dead from B4 to the next h1' gather)
+    static constexpr int L_LG = L_H1;               // [R][32] MOL: the 30 fc3 outputs of every batch row, in window 5 (H1 is dead from B4 to the next pair gather)
     static constexpr int L_MISC = L_XN + 16;
     static constexpr int L_PROF = L_MISC + 16;      // [2 roles][24]: phase cycles of wave 0 (C) and wave 4 (S), instrumented build only
     static constexpr int L_TOTAL = L_PROF + 48;
     static_assert(L_TOTAL * 4 <= 163840, "LDS budget");
     static_assert((L_P % 4) == 0, "B operands are read as 16-byte vectors");
+    // mailbox regions per team, in 4-byte words; every region is double-buffered by step parity
+    static constexpr unsigned RGD = (unsigned)VEC;                       // one published vector of words
+    static constexpr unsigned M_XH = 0;                                  // {x2, h1'} pairs: 2 parities x 2 RGD
+    static constexpr unsigned M_X3 = 4 * RGD, M_F1 = 6 * RGD, M_F2 = 8 * RGD;   // 2 parities x RGD each
+    static constexpr unsigned M_PR = 10 * RGD;                           // race candidates: 2 parities x PRG granules of 8 bytes
+    static constexpr unsigned PRG = (unsigned)R * 256u;                  // [row][32 workgroups][8 waves] (CS_FC3_SPLIT_RAW; else [row][32][4 C waves], half of it used)
+    static constexpr unsigned MAIL_WORDS = M_PR + 2 * 2 * PRG;
+    static_assert(MAIL_WORDS <= 2 * WRNN_BATCH_MAIL_GRANULES, "mailbox budget");
+    static constexpr int NMP = R;                   // 16-byte loads per thread (256 threads) of a pair vector
+    static constexpr int NMW = R / 2;               //                                          of a word vector
 };
 // hand-over slots
 constexpr int H_GH1R = 0, H_GH1Z = 1, H_GH1N = 2, H_CDX = 3, H_CDY = 4, H_CDZ = 5, H_CDW = 6, H_GH2R = 7, H_GH2Z = 8, H_GH2N = 9,
               H_C2R = 10, H_C2Z = 11, H_C2N = 12, H_C3 = 13, H_C4 = 14, H_NZ = 15;   // H_NZ: [parity][2]
 
-// sentinel first, then everything: a C / S wave has nothing to do between its publish and this gather, and a poll that opens with a
-// full look re-reads R x 4 KB per workgroup while the producers' stores queue behind those reads.  The full look
-// goes out as soon as CS_EARLY_LOOK of the sentinel slice's 64 lanes carry the step's tag: the stragglers' granules land while it is
-// in flight, so the sentinel round trip and the data round trip overlap (round 4: +2.1 % / +4.4 %).
-template <int NM>
-__device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], bool &dead,
-                                          unsigned *err, unsigned code, unsigned *sent_cyc = nullptr) {
+__device__ __forceinline__ void st_word(unsigned *base, unsigned idx, unsigned v) {
+    const unsigned off = idx * 4u;
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void st_pair(unsigned *base, unsigned idx, unsigned lo, unsigned hi) {   // idx: word index of the pair (even)
+    const u64 v = ((u64)hi << 32) | lo;
+    const unsigned off = idx * 4u;
+    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+// has every word of a 16-byte load arrived?  (a pair arrives whole: one 8-byte store -- its first word stands for both)
+template <bool PAIR>
+__device__ __forceinline__ bool arrived(const u4v &v) {
+    return PAIR ? (v.x != CS_EMPTY && v.z != CS_EMPTY) : (v.x != CS_EMPTY && v.y != CS_EMPTY && v.z != CS_EMPTY && v.w != CS_EMPTY);
+}
+// All-gather of one published vector: NL 16-byte sc1 loads per thread (voff = thread * 16, soff = the vector's byte offset).
+// Sentinel first, then everything: a C wave has nothing (or little) to do between its publish and this gather, and a poll that opens
+// with a full look re-reads the whole vector per workgroup while the producers' stores queue behind those reads.
+// The sentinel is the vector's last 4 KB (words of all 32 producers); the full look goes out as soon as CS_EARLY_LOOK of its 64 lanes hold
+// data: the stragglers' words land while it is in flight, so the sentinel round trip and the data round trip overlap (round 4: +2.1 % /
+// +4.4 %).  A look that still comes back incomplete polls the sentinel until it is complete and then fetches everything again: no
+// per-slice state (the retry masks of the first version cost ~16 SGPR pairs).  Every spin is bounded.
+typedef volatile int __attribute__((address_space(3))) *lds_vip;
+template <int NL, bool PAIR, bool SENTINEL = true>
+__device__ __forceinline__ void gather_words(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u4v (&g)[NL], bool &dead, unsigned *err, unsigned code,
+                                             unsigned *sent_cyc = nullptr, lds_vip hold = nullptr) {
     unsigned spins = 0;
-    for (;;) {
-        const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
+    while (SENTINEL) {
+        const u4v sv = ld_pair(rs, voff, soff + (NL - 1) * 4096u);
 #if CS_EARLY_LOOK
-        if (__builtin_popcountll(__ballot(sv.y == tag && sv.w == tag)) >= CS_EARLY_LOOK || dead) break;
+        if (__builtin_popcountll(__ballot(arrived<PAIR>(sv))) >= CS_EARLY_LOOK || dead) break;
 #else
-        if (__all(sv.y == tag && sv.w == tag) || dead) break;
+        if (__all(arrived<PAIR>(sv)) || dead) break;
 #endif
         if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
         __builtin_amdgcn_s_sleep(1);
     }
     if (sent_cyc) *sent_cyc = (unsigned)__builtin_readcyclecounter();   // instrumented build: the sentinel wait ends here, the data look starts
-    const unsigned offs[1] = {soff};
-    gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
+    if (hold && (threadIdx.x & 63) == 0) *hold = 0;                      // CS_YIELD 2: the S wave of this SIMD holds its MFMAs while the look is checked and written
+    for (;;) {
+#pragma unroll
+        for (int m = 0; m < NL; ++m) g[m] = ld_pair(rs, voff, soff + m * 4096u);
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < NL; ++m) ok = ok && arrived<PAIR>(g[m]);
+        if (__all(ok) || dead) break;
+        for (;;) {
+            if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+            __builtin_amdgcn_s_sleep(1);
+            const u4v sv = ld_pair(rs, voff, soff + (NL - 1) * 4096u);
+            if (__all(arrived<PAIR>(sv))) break;
+        }
+        if (dead) break;
+    }
 }
 
 // one set of 4 fc3 rows (A-operand image `w3s` in LDS: [8 slabs][64 lanes] f4) times the gathered fc2 outputs: the thread's folded logit
@@ -173,6 +252,44 @@ __device__ __forceinline__ float fc3_one_set(lds_cf4p w3s, lds_cf4p xv, int my_r
     return lg;
 }
 
+// RAW sampler, in-wave part: (v, k) = score and class of this lane's candidate for its batch row -> the best of the wave's classes for that row
+// (the four unit groups rho = lane >> 4), ties -> the lower class.  Valid in the lanes with rho == 0.
+__device__ __forceinline__ void race_fold(float &v, int &k) {
+    {
+        const u2v pv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const u2v pk = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
+        const int ka = (int)pk.x, kb = (int)pk.y;
+        const bool tb = vb > va || (vb == va && kb < ka);
+        v = tb ? vb : va; k = tb ? kb : ka;
+    }
+    {
+        const u2v pv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const u2v pk = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+        const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
+        const int ka = (int)pk.x, kb = (int)pk.y;
+        const bool tb = vb > va || (vb == va && kb < ka);
+        v = tb ? vb : va; k = tb ? kb : ka;
+    }
+}
+// ... and the winner among a row's candidates {tag | class, score}: lane l holds slots 2 l, 2 l + 1 (one 16-byte load: 128 candidates, one per C wave) or
+// 4 l .. 4 l + 3 (two loads: 256, one per wave, CS_FC3_SPLIT_RAW); slots are in class order (workgroup, wave pair, C before S), so "the first of equal
+// scores" is the lowest class, as torch's argmax of p / q picks it
+template <bool TWO>
+__device__ __forceinline__ int race_winner(const u4v &ga, const u4v &gb) {
+    float best = __uint_as_float(ga.x);
+    unsigned bk = ga.y;
+    { const float v = __uint_as_float(ga.z); if (v > best) { best = v; bk = ga.w; } }
+    if (TWO) {
+        { const float v = __uint_as_float(gb.x); if (v > best) { best = v; bk = gb.y; } }
+        { const float v = __uint_as_float(gb.z); if (v > best) { best = v; bk = gb.w; } }
+    }
+    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
+    const u64 ball = __ballot(best == mx);
+    const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
+    return __builtin_amdgcn_readlane((int)(bk & 1023u), src);
+}
+
 }  // namespace
 
 #define PBW(i)                                                                 \
@@ -197,12 +314,13 @@ __device__ __forceinline__ float fc3_one_set(lds_cf4p w3s, lds_cf4p xv, int my_r
 
 template <int MODE, int NQ, bool PROF>
 __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs a) {
-    typedef Lay<NQ> LM;       // mailbox regions (shared with loop_batch.hip)
     typedef LayCS<NQ> L;
-    constexpr int R = L::R, NM = LM::NM, SL = L::SL;
+    constexpr int R = L::R, NMP = L::NMP, NMW = L::NMW, SL = L::SL;
     constexpr int DG = NQ == 1 ? 2 : 1, DS = NQ == 1 ? 4 : 2, D3 = NQ == 1 ? 2 : 1;
+    // fc3: the 8 sets of four rows a SIMD owns are shared between its two waves -- the C wave evaluates classes 8 wl + iu, the S wave 8 wl + iu + 4
+    // (the fc3 image is in LDS, so either wave can): half the MFMAs each, side by side on the matrix pipe, instead of all of them in the C wave
+    constexpr bool FC3_SPLIT = MODE == WRNN_MODE_MOL ? CS_FC3_SPLIT != 0 : CS_FC3_SPLIT_RAW != 0;
     // rows whose race a C wave finishes itself: RAW at 8 rows per team hands the second one (batch row wl + 4) to the S wave of its SIMD
-    constexpr bool FC3_SPLIT = MODE == WRNN_MODE_MOL && CS_FC3_SPLIT;
     constexpr int NBC = (MODE == WRNN_MODE_RAW && NQ == 2 && CS_SPLIT_WIN) ? 1 : NQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
@@ -260,6 +378,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const int n_batches = (a.n_rows + a.rpb - 1) / a.rpb;
     if (g >= TB_WGS || team >= a.n_teams || team >= n_batches) return;
     u64 *mail = a.mail + (size_t)team * WRNN_BATCH_MAIL_GRANULES;
+    unsigned *mailw = (unsigned *)mail;   // the same bytes in words (pairs and words: LayCS::M_*; the race candidates stay 8-byte granules)
     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)mail, 0, (int)(WRNN_BATCH_MAIL_GRANULES * 8u), 0x00020000);
 
     const int unit = 16 * g + 4 * wl + iu;
@@ -317,16 +436,25 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const lds_cfp cst = (lds_cfp)(size_t)launder(smem_base + (unsigned)L::L_CST * 4u + (unsigned)ci * 4u);
     typedef float __attribute__((address_space(3))) *lds_fp;
     const lds_fp hand = (lds_fp)(size_t)launder(smem_base + (unsigned)L::L_HAND * 4u + (unsigned)ci * 4u);
+    // where a thread's loads of a gathered vector go (B-operand order [rq][S][kp][j][e]; thread tl, 16-byte load m):
+    //   pairs (8-byte entries, mailbox order [rq][wl][S][iu][j][e]): load m = (rq, wl) = (m >> 2, m & 3), the thread's two entries are e, e + 1 -> one 8-byte write
+    //   words: load m covers (rq, wl) = (m >> 1, 2 (m & 1) + (tl >> 7)), the thread's four words are e = 0..3 -> one 16-byte write
     const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + 2u * (unsigned)(tl & 31)) * 4u);
+    typedef f4 __attribute__((address_space(3))) *lds_f4p;
+    const lds_f4p gd4 = (lds_f4p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)((tl >> 4) & 7) * 64u + (unsigned)(tl >> 7) * 16u + (unsigned)(tl & 15)) * 16u);
 
-    // S-wave meeting point (epoch of the H1 each S wave has written): LDS-address-space pointers, so that the flag is stored and polled with DS
-    // instructions (round-4 advisor: through generic `volatile` pointers hipcc emitted flat_store / flat_load, which the memory model does not
-    // order against the ds_write of the data).  A wave's DS instructions execute in order, and the LDS serves the waves' instructions one after
-    // the other: a wave that has read the flag with a DS read reads the data behind it.
+    // LDS words two waves talk through, addressed in the LDS address space so that they are stored and polled with DS instructions (round-4
+    // advisor: through generic `volatile` pointers hipcc emitted flat_store / flat_load, which the memory model does not order against the
+    // ds_write of the data; a wave's DS instructions execute in order and the LDS serves the waves' instructions one after the other):
+    //   tok[wl]   CS_YIELD: C wave wl -> S wave wl of the same SIMD: 1 = "I multiply or wait for a sentinel: the matrix pipe is yours too", 0 = "hold"
+    //   sflag[4]  CS_PAIR 0: meeting point of the four S waves (epoch of the H1 each of them has written)
     typedef int i4v __attribute__((ext_vector_type(4)));
-    typedef volatile int __attribute__((address_space(3))) *lds_vip;
     typedef volatile i4v __attribute__((address_space(3))) *lds_vi4p;
+    const lds_vip tok = (lds_vip)(size_t)(smem_base + (unsigned)(L::L_MISC + 4 + wl) * 4u);
     const lds_vip sflag = (lds_vip)(size_t)(smem_base + (unsigned)(L::L_MISC + 8) * 4u);
+    auto tok_set = [&](int v) { if (CS_YIELD && lane == 0) *tok = v; };
+    const lds_vip hold2 = CS_YIELD == 2 ? tok : nullptr;
+    if (CS_YIELD && !isC && lane == 0) *tok = 1;
     bool dead = false;
     unsigned epoch = 0;
     unsigned *prof_lds = (unsigned *)(lds + L::L_PROF);
@@ -348,6 +476,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
         if (isC) {
             // =========================================== C: the serial chain ===========================================
             float h1 = 0.0f, h2 = 0.0f, x2own = 0.0f;
+            float gh2n = cst[C_H2N * SL];   // CS_WN_ON_C: gate n of W_hh2.h2' + b_hh2, evaluated by this wave a step ahead (step 0: h2 = 0, :194-196)
             int frow[NQ];
             int fsteps[NQ];
 #pragma unroll
@@ -374,20 +503,35 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     h1 = (1.0f - zg) * ng + zg * h1;
                     x2own = xin + h1;
                     if (primary) {
-                        st_granule(mail, LM::G_X2 + par * LM::RG + mb_own, epoch, __float_as_uint(x2own));
-                        st_granule(mail, LM::G_H1 + par * LM::RG + mb_own, epoch, __float_as_uint(h1));
+                        if (CS_PAIR) st_pair(mailw, L::M_XH + par * 2u * L::RGD + 2u * mb_own, __float_as_uint(x2own), __float_as_uint(h1));
+                        else {   // two word vectors: x2 for the C waves' look, h1' for the S waves' (behind B1)
+                            st_word(mailw, L::M_XH + par * 2u * L::RGD + mb_own, __float_as_uint(x2own));
+                            st_word(mailw, L::M_XH + par * 2u * L::RGD + L::RGD + mb_own, __float_as_uint(h1));
+                        }
                     }
                 }
                 PBW(0);
-                {
-                    u4v gx[1][NM];
+                if (CS_PAIR) {
+                    u4v gx[NMP];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 21u GSF_TS);
+                    gather_words<NMP, true>(mrs, gvoff, (L::M_XH + par * 2u * L::RGD) * 4u, gx, dead, a.err, 21u GSF_TS);
                     GSF_ACC(17);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NMP; ++m) {   // x2 -> P, h1' -> H1 (the S waves multiply it from B1 on)
+                        gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[m].x), __uint_as_float(gx[m].z)};
+                        gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[m].y), __uint_as_float(gx[m].w)};
+                    }
+                } else {
+                    u4v gx[NMW];
+                    GSF_DECL;
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_XH + par * 2u * L::RGD) * 4u, gx, dead, a.err, 21u GSF_TS);
+                    GSF_ACC(17);
+                    PBW(1);
+#pragma unroll
+                    for (int m = 0; m < NMW; ++m) gd4[0 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
+                tok_set(CS_YIELD == 3 ? 0 : 1);
                 PBW(2);
                 __syncthreads();   // B1
                 PBW(3);
@@ -400,6 +544,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) acc[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
                     mfma_gates<NQ, 3, false, DG>(wv, vP, acc, NoMid());
+                    if (CS_YIELD != 3) tok_set(0);   // the fold and the gates are a dependent VALU chain: beside an MFMA stream they take three times as long (session 1)
                     PBW(4);
                     float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
@@ -410,20 +555,26 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     PBW(5);
                     const float rg = sigmoid_fast((tr + hand[H_C2R * SL]) + hand[H_GH2R * SL]);
                     const float zg = sigmoid_fast((tz + hand[H_C2Z * SL]) + hand[H_GH2Z * SL]);
-                    const float ng = tanh_fast((tn + hand[H_C2N * SL]) + rg * hand[H_GH2N * SL]);
+                    const float ng = tanh_fast((tn + hand[H_C2N * SL]) + rg * (CS_WN_ON_C ? gh2n : hand[H_GH2N * SL]));
                     h2 = (1.0f - zg) * ng + zg * h2;
                     const float x3 = x2own + h2;
-                    if (primary) st_granule(mail, LM::G_X3 + par * LM::RG + mb_own, epoch, __float_as_uint(x3));
+                    if (primary) st_word(mailw, L::M_X3 + par * L::RGD + mb_own, __float_as_uint(x3));
+                    tok_set(1);   // from here the wave waits for a sentinel
                 }
                 PBW(6);
                 {
-                    u4v gx[1][NM];
+                    u4v gx[NMW];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_X3 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 23u GSF_TS);
+#if CS_PROF_SPLIT
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_X3 + par * L::RGD) * 4u, gx, dead, a.err, 23u GSF_TS, hold2);
+#else
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_X3 + par * L::RGD) * 4u, gx, dead, a.err, 23u, nullptr, hold2);
+#endif
                     GSF_ACC(7);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(1 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NMW; ++m) gd4[1 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
+                tok_set(1);
                 PBW(9);
                 __syncthreads();   // B2
                 PBW(10);
@@ -432,23 +583,66 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 {
                     f4 sum[NQ];
                     mfma_single<NQ, (NQ == 1 ? 4 : 2), false, DS>(wv + 96, vQ, sum);
+                    if (CS_YIELD != 3) tok_set(0);
                     float s = 0.f;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const float f = fold_kp(sum[q]);
                         if (q == 0 || my_rq == q) s = f;
                     }
-                    if (primary) st_granule(mail, LM::G_F1 + par * LM::RG + mb_own, epoch, __float_as_uint(fmaxf(s + hand[H_C3 * SL], 0.0f)));
+                    if (primary) st_word(mailw, L::M_F1 + par * L::RGD + mb_own, __float_as_uint(fmaxf(s + hand[H_C3 * SL], 0.0f)));
+                    tok_set(1);
                 }
                 PBW(11);
+                if (CS_WN_ON_C) {
+                    // gate n of gh2' = W_hh2.(x3 - x2) + b_hh2 for the NEXT step (A operands: the LDS image of the S waves' round-4 product), while the
+                    // fc1 words travel: a publish is visible everywhere ~600-800 cycles after the store at the earliest, these 32 NQ MFMAs + fold take
+                    // about that.  Q (x3) and P (x2) are both intact in window 3.
+                    __builtin_amdgcn_sched_barrier(0);
+                    f4 accn[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) accn[q] = (f4){0.f, 0.f, 0.f, 0.f};
+                    f4 xq[NQ], xp[NQ], wn = wnl[0];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
+#pragma unroll
+                    for (int S = 0; S < 8; ++S) {
+                        f4 b[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
+                        const f4 wcur = wn;
+                        if (S < 7) {
+                            wn = wnl[(S + 1) * 64];
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8 + S + 1) * 64]; xp[q] = vP[(q * 8 + S + 1) * 64]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) accn[q] = mfma4(wcur[e], b[q][e], accn[q]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float fn = fold_kp(accn[q]);
+                        if (q == 0 || my_rq == q) gh2n = fn + cst[C_H2N * SL];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 {
-                    u4v gx[1][NM];
+                    u4v gx[NMW];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 24u GSF_TS);
+#if CS_PROF_SPLIT
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_F1 + par * L::RGD) * 4u, gx, dead, a.err, 24u GSF_TS, hold2);
+#else
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_F1 + par * L::RGD) * 4u, gx, dead, a.err, 24u, nullptr, hold2);
+#endif
                     GSF_ACC(12);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NMW; ++m) gd4[2 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
+                tok_set(1);
                 PBW(13);
                 __syncthreads();   // B3
                 PBW(14);
@@ -463,16 +657,16 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         const float f = fold_kp(sum[q]);
                         if (q == 0 || my_rq == q) s = f;
                     }
-                    if (primary) st_granule(mail, LM::G_F2 + par * LM::RG + mb_own, epoch, __float_as_uint(fmaxf(s + hand[H_C4 * SL], 0.0f)));
+                    if (primary) st_word(mailw, L::M_F2 + par * L::RGD + mb_own, __float_as_uint(fmaxf(s + hand[H_C4 * SL], 0.0f)));
                 }
                 PBW(15);
                 {
-                    u4v gx[1][NM];
+                    u4v gx[NMW];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u GSF_TS);
+                    gather_words<NMW, false>(mrs, gvoff, (L::M_F2 + par * L::RGD) * 4u, gx, dead, a.err, 25u GSF_TS);
                     GSF_ACC(16);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NMW; ++m) gd4[0 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                 }
                 PBW(18);
                 __syncthreads();   // B4
@@ -482,10 +676,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 {
                     float lg0 = 0.f, lg1 = 0.f;
                     if (FC3_SPLIT) {
-                        // MOL: the 8 sets of four fc3 rows are shared between the two waves of a SIMD -- this wave evaluates classes 8 wl + iu,
-                        // the S wave 8 wl + iu + 4 (the fc3 image is in LDS, so either wave can): 32 MFMAs each, side by side, instead of 64 here
-                        lg0 = fc3_one_set<NQ, D3>(w3, vP, my_rq) + cst[C_B30 * SL];
-                        if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 < NC)
+                        // this wave's half: classes 8 wl + iu of the workgroup's slice (RAW) / of all 30 rows (MOL); the S wave of the SIMD: + 4
+                        if (wg_has_fc3) lg0 = fc3_one_set<NQ, D3>(w3, vP, my_rq) + cst[C_B30 * SL];
+                        if (a.logits_out && primary && row_ok && t < rw.steps && (MODE != WRNN_MODE_MOL || g == 0) && cls0 < NC)
                             a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0] = lg0;
                     } else if (wg_has_fc3) {
                         constexpr int NP = NQ == 1 ? 2 : 1;
@@ -541,30 +734,17 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     }
                     if (MODE == WRNN_MODE_RAW) {
                         const lds_fp hz = hand + (H_NZ + 2 * par) * SL;
-                        const float nz0 = hz[0], nz1 = hz[SL];
-                        float v = cls0 < NC ? lg0 + nz0 : -INFINITY;
+                        float v = cls0 < NC ? lg0 + hz[0] : -INFINITY;
                         int k = cls0;
-                        const float v1 = cls0 + 4 < NC ? lg1 + nz1 : -INFINITY;
-                        if (v1 > v) { v = v1; k = cls0 + 4; }
-                        {
-                            const u2v pv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                            const u2v pk = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
-                            const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
-                            const int ka = (int)pk.x, kb = (int)pk.y;
-                            const bool tb = vb > va || (vb == va && kb < ka);
-                            v = tb ? vb : va; k = tb ? kb : ka;
+                        if (!FC3_SPLIT) {
+                            const float v1 = cls0 + 4 < NC ? lg1 + hz[SL] : -INFINITY;
+                            if (v1 > v) { v = v1; k = cls0 + 4; }
                         }
-                        {
-                            const u2v pv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                            const u2v pk = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
-                            const float va = __uint_as_float(pv.x), vb = __uint_as_float(pv.y);
-                            const int ka = (int)pk.x, kb = (int)pk.y;
-                            const bool tb = vb > va || (vb == va && kb < ka);
-                            v = tb ? vb : va; k = tb ? kb : ka;
+                        race_fold(v, k);
+                        if (primary && rho == 0) {
+                            const unsigned slot = L::M_PR / 2u + par * L::PRG + (unsigned)rb * 256u + (FC3_SPLIT ? (unsigned)(g * 8 + wl * 2) : (unsigned)(g * 4 + wl));
+                            st_granule(mail, slot, (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
                         }
-                        if (primary && rho == 0)
-                            st_granule(mail, LM::G_PR + par * LM::PRG + (unsigned)rb * 128u + (unsigned)(g * 4 + wl),
-                                       (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
                     } else {
                         // MOL: the wave's 8 fc3 outputs of every batch row -> LDS; wave w samples batch rows w, w + 4 behind the barrier
                         if (primary) { lgt[rb * 32 + cls0] = lg0; if (!FC3_SPLIT) lgt[rb * 32 + cls0 + 4] = lg1; }
@@ -572,16 +752,21 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 }
                 PBW(20);
                 if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b
-                u4v gqa[NBC];
+                u4v gqa[NBC][2];
                 if (MODE == WRNN_MODE_RAW) {
                     const unsigned tg = epoch & 0x3fffffu;
                     unsigned spins = 0;
                     for (;;) {
 #pragma unroll
-                        for (int i = 0; i < NBC; ++i) gqa[i] = ld_pair(mrs, (unsigned)lane * 16u, (LM::G_PR + par * LM::PRG + (unsigned)(wl + 4 * i) * 128u) * 8u);
+                        for (int i = 0; i < NBC; ++i) {
+                            const unsigned cb = (L::M_PR / 2u + par * L::PRG + (unsigned)(wl + 4 * i) * 256u) * 8u;
+                            gqa[i][0] = ld_pair(mrs, (unsigned)lane * (FC3_SPLIT ? 32u : 16u), cb);
+                            gqa[i][1] = FC3_SPLIT ? ld_pair(mrs, (unsigned)lane * 32u, cb + 16u) : gqa[i][0];
+                        }
                         bool ok = true;
 #pragma unroll
-                        for (int i = 0; i < NBC; ++i) ok = ok && (gqa[i].y >> 10) == tg && (gqa[i].w >> 10) == tg;
+                        for (int i = 0; i < NBC; ++i)
+                            ok = ok && (gqa[i][0].y >> 10) == tg && (gqa[i][0].w >> 10) == tg && (gqa[i][1].y >> 10) == tg && (gqa[i][1].w >> 10) == tg;
                         if (__all(ok) || dead) break;
                         if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 26u); break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -604,15 +789,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     float x_new;
                     int lab;
                     if (MODE == WRNN_MODE_RAW) {
-                        const u4v gq = gqa[bi];
-                        const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
-                        const bool pb = vb > va;
-                        const float best = pb ? vb : va;
-                        const int besti = (int)((pb ? gq.w : gq.y) & 1023u);
-                        const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
-                        const u64 ball = __ballot(best == mx);
-                        const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
-                        lab = __builtin_amdgcn_readlane(besti, src);
+                        lab = race_winner<FC3_SPLIT>(gqa[bi][0], gqa[bi][1]);
                         x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
                     } else {
                         // sample_from_discretized_mix_logistic (distribution.py:87-123) for batch row `brow`
@@ -756,49 +933,64 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 const unsigned par = epoch & 1u;
                 if (PROF) prof_last = (unsigned)__builtin_readcyclecounter();
 
-                // ---------------- window 1: the sampler's noise of THIS step, while the C waves wait for x2 (an S wave has nothing else to do
-                // before B1; in window 4, behind the W_hh2 fold, it made the S waves late at B4) ----------------
+                // ---------------- window 1: the sampler's noise of THIS step, while the C waves wait for the {x2, h1'} pairs (an S wave has nothing
+                // else to do before B1; in window 4 of the step before it made the S waves late at B4) ----------------
                 noise_step(t, par);
                 PBW(2);
-                __syncthreads();   // B1
+                __syncthreads();   // B1: the C waves have written x2 -> P and h1' -> H1
                 PBW(3);
-                {
-                    if (CS_SPRIO) __builtin_amdgcn_s_setprio(3);   // the gather + meeting point at the C waves' priority
-                    // h1' is not needed before this wave's own W_hh1 product: fetched HERE, behind B1, the S waves are never the last to reach B1
-                    // (they were: their 32 KB look ran beside the C waves' x2 look through the same 64 B/clk port) and the x2 look has the port
-                    // to itself.  The data was published a whole window ago: one look, no sentinel.  The four S waves then meet through LDS
-                    // flags (s_barrier would need the C waves).
-                    u4v gx[1][NM];
-                    const unsigned offs[1] = {(LM::G_H1 + par * LM::RG) * 8u};
-                    gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
+                // The C waves have gathered this step's x2 from all 32 workgroups: everybody has finished every read of the PREVIOUS step.  Its words (other
+                // parity) are emptied by their producer's S lane -- same lane = same (unit, row) = same word as the C lane that published it -- off the
+                // serial chain (session 2: issued by the C waves with their x3 publish, the five stores cost the x3 exchange ~550 cycles; session 3: in
+                // front of the S waves' own h1' look they cost THAT look ~800 cycles -- a wave's loads are counted behind its stores -- so behind it).
+                auto empty_previous = [&]() {
+                    if (primary) {
+                        const unsigned op = par ^ 1u;
+                        if (CS_PAIR) st_pair(mailw, L::M_XH + op * 2u * L::RGD + 2u * mb_own, CS_EMPTY, CS_EMPTY);
+                        else { st_word(mailw, L::M_XH + op * 2u * L::RGD + mb_own, CS_EMPTY); st_word(mailw, L::M_XH + op * 2u * L::RGD + L::RGD + mb_own, CS_EMPTY); }
+                        st_word(mailw, L::M_X3 + op * L::RGD + mb_own, CS_EMPTY);
+                        st_word(mailw, L::M_F1 + op * L::RGD + mb_own, CS_EMPTY);
+                        st_word(mailw, L::M_F2 + op * L::RGD + mb_own, CS_EMPTY);
+                    }
+                };
+                if (CS_PAIR) empty_previous();
+                // an S wave looks at the token of the C wave it shares the SIMD with in front of every slab (CS_YIELD)
+                auto yield = [&]() {
+                    if (CS_YIELD) { for (unsigned sp = 0; sp < 20000u && *tok == 0; ++sp) __builtin_amdgcn_s_sleep(1); }
+                };
+                if (!CS_PAIR) {
+                    // h1' gathered by the S waves themselves, BEHIND B1 (round 4: their look no longer runs beside the C waves' x2 look through the same
+                    // 64 B/clk port, and they are never the last at B1).  The words were published a whole window ago: one look, no sentinel.  The four S
+                    // waves then meet through LDS flags (s_barrier would need the C waves).
+                    __builtin_amdgcn_s_setprio(3);
+                    u4v gx[NMW];
+                    gather_words<NMW, false, false>(mrs, gvoff, (L::M_XH + par * 2u * L::RGD + L::RGD) * 4u, gx, dead, a.err, 22u);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int m = 0; m < NMW; ++m) gd4[2 * (L::VEC / 4) + (m >> 1) * 512 + (m & 1) * 32] = __builtin_bit_cast(f4, gx[m]);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's part of H1 has left the DS queue
                     if (lane == 0) sflag[wl] = (int)epoch;
-                    PBW(5);   // h1' written to LDS
+                    PBW(5);
                     unsigned sp = 0;
                     for (;;) {
                         const i4v f = *(lds_vi4p)sflag;
                         if ((f.x == (int)epoch && f.y == (int)epoch && f.z == (int)epoch && f.w == (int)epoch) || dead) break;
                         if (++sp > 200000u) { dead = true; if (lane == 0) atomicExch(a.err, 29u); break; }   // a lost S wave: reported, not multiplied through
-                        if (CS_FLAG_POLL_SLEEP) __builtin_amdgcn_s_sleep(CS_FLAG_POLL_SLEEP);
                     }
                     asm volatile("" ::: "memory");
-                    PBW(6);   // the four S waves have met
-                    if (CS_SPRIO) __builtin_amdgcn_s_setprio(0);
+                    PBW(6);
+                    __builtin_amdgcn_s_setprio(0);
+                    empty_previous();
                 }
-
-                // ---------------- windows 2 - 4: gh1' = W_hh1 . h1' + b_hh1 and gh2' = W_hh2 . (x3 - x2) + b_hh2 of the next step ----------------
-                // The MFMAs of a product run in "its" window (they read H1 resp. Q / P, which the C waves overwrite at the end of the next
-                // one); its FOLD -- pure register work, ~700 cycles at 8 rows -- runs behind the barrier, at the start of the next window:
-                // with the fold in front of B2 the S waves were the last to arrive there (B2 wait of the C waves 390 cycles + a stretched
-                // x3 exchange), and the same at B3.  The hand-over slots are read by C a whole step later.
-                f4 acc1[3][NQ], acc2[3][NQ];
+                constexpr int NG2 = CS_WN_ON_C ? 2 : 3;
+                f4 acc1[3][NQ], acc2[NG2][NQ];
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt)
+                for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) { acc1[gt][q] = (f4){0.f, 0.f, 0.f, 0.f}; acc2[gt][q] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                    for (int gt = 0; gt < 3; ++gt) acc1[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int gt = 0; gt < NG2; ++gt) acc2[gt][q] = (f4){0.f, 0.f, 0.f, 0.f};
+                }
                 auto fold1 = [&]() {
                     float gr = 0.f, gz = 0.f, gn = 0.f;
 #pragma unroll
@@ -806,97 +998,119 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         const float fr = fold_kp(acc1[0][q]), fz = fold_kp(acc1[1][q]), fn = fold_kp(acc1[2][q]);
                         if (q == 0 || my_rq == q) { gr = fr + cst[C_H1R * SL]; gz = fz + cst[C_H1Z * SL]; gn = fn + cst[C_H1N * SL]; }
                     }
-                    if (primary) { hand[H_GH1R * SL] = gr; hand[H_GH1Z * SL] = gz; hand[H_GH1N * SL] = gn; }
+                    if (primary) { hand[H_GH1R * SL] = gr; hand[H_GH1Z * SL] = gz; hand[H_GH1N * SL] = gn; }   // read by C in phase A of the next step
                 };
                 auto fold2 = [&]() {
                     float gr = 0.f, gz = 0.f, gn = 0.f;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const float fr = fold_kp(acc2[0][q]), fz = fold_kp(acc2[1][q]), fn = fold_kp(acc2[2][q]);
-                        if (q == 0 || my_rq == q) { gr = fr + cst[C_H2R * SL]; gz = fz + cst[C_H2Z * SL]; gn = fn + cst[C_H2N * SL]; }
+                        const float fr = fold_kp(acc2[0][q]), fz = fold_kp(acc2[1][q]);
+                        if (q == 0 || my_rq == q) { gr = fr + cst[C_H2R * SL]; gz = fz + cst[C_H2Z * SL]; }
+                        if (!CS_WN_ON_C) { const float fn = fold_kp(acc2[NG2 - 1][q]); if (q == 0 || my_rq == q) gn = fn + cst[C_H2N * SL]; }
                     }
-                    if (primary) { hand[H_GH2R * SL] = gr; hand[H_GH2Z * SL] = gz; hand[H_GH2N * SL] = gn; }
+                    if (primary) { hand[H_GH2R * SL] = gr; hand[H_GH2Z * SL] = gz; if (!CS_WN_ON_C) hand[H_GH2N * SL] = gn; }   // read by C in window 2 of the next step
                 };
-                if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : 1)>(wv, vH1, acc1, NoMid());
+                if (CS_SMPRIO) __builtin_amdgcn_s_setprio(CS_SMPRIO);
+                if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : 1), decltype(yield), 0, (CS_YIELD != 0)>(wv, vH1, acc1, yield);
+                if (CS_SMPRIO) __builtin_amdgcn_s_setprio(0);
                 PBW(7);
+                if (!CS_LATE_FOLD) fold1();
                 PBW(8);
-                __syncthreads();   // B2
+                __syncthreads();   // B2: x3 -> Q
                 PBW(10);
-                fold1();
-                if (!(CS_DIAG & 2)) {
-                    f4 xq[NQ], xp[NQ], wn = wnl[0];
+                if (CS_LATE_FOLD) fold1();
+
+                // ---------------- window 3: gh2' = W_hh2 . (x3 - x2) + b_hh2 of the next step: gates r, z (the weights in this wave's registers);
+                // gate n (A operands in LDS) is the C wave's, between its fc1 publish and its fc1 look (CS_WN_ON_C) ----------------
+                {
+                    if (CS_SMPRIO) __builtin_amdgcn_s_setprio(CS_SMPRIO);
+                    if (!(CS_DIAG & 2)) {
+                        f4 xq[NQ], xp[NQ], wn = (f4){0.f, 0.f, 0.f, 0.f};
+                        if (!CS_WN_ON_C) wn = wnl[0];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
+                        for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
 #pragma unroll
-                    for (int S = 0; S < 8; ++S) {
-                        f4 b[NQ];
+                        for (int S = 0; S < 8; ++S) {
+                            yield();
+                            f4 b[NQ];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
-                        const f4 wcur = wn;
-                        if (S < 7) {
-                            wn = wnl[(S + 1) * 64];
+                            for (int q = 0; q < NQ; ++q) b[q] = xq[q] - xp[q];
+                            const f4 wcur = wn;
+                            if (S < 7) {
+                                if (!CS_WN_ON_C) wn = wnl[(S + 1) * 64];
 #pragma unroll
-                            for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8 + S + 1) * 64]; xp[q] = vP[(q * 8 + S + 1) * 64]; }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float wr = wv[96 + 4 * S + e], wz = wv[128 + 4 * S + e];
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) {
-                                acc2[0][q] = mfma4(wr, b[q][e], acc2[0][q]);
-                                acc2[1][q] = mfma4(wz, b[q][e], acc2[1][q]);
-                                acc2[2][q] = mfma4(wcur[e], b[q][e], acc2[2][q]);
+                                for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8 + S + 1) * 64]; xp[q] = vP[(q * 8 + S + 1) * 64]; }
                             }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float wr = wv[96 + 4 * S + e], wz = wv[128 + 4 * S + e];
+#pragma unroll
+                                for (int q = 0; q < NQ; ++q) {
+                                    acc2[0][q] = mfma4(wr, b[q][e], acc2[0][q]);
+                                    acc2[1][q] = mfma4(wz, b[q][e], acc2[1][q]);
+                                    if (!CS_WN_ON_C) acc2[NG2 - 1][q] = mfma4(wcur[e], b[q][e], acc2[NG2 - 1][q]);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (CS_SMPRIO) __builtin_amdgcn_s_setprio(0);
+                    PBW(12);
+                    if (!CS_LATE_FOLD) fold2();
                 }
-                PBW(12);
+                // the CS_EMPTY stores of window 2 must have reached the L2 before anybody polls their parity again (next step).  They have, thousands of
+                // cycles ago -- made certain HERE: behind B3 the C waves publish fc2, and nobody enters the next step without having gathered that.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PBW(13);
                 __syncthreads();   // B3
                 PBW(14);
-                fold2();
+                if (CS_LATE_FOLD) fold2();
 
-                // ---------------- window 4 (MOL: the conditioning of the next step) ----------------
-                if (CS_COND_W4 && t + 1 < bsteps) cond_step(t + 1);   // the cd slots are read in phase A of the next step only
+                // ---------------- window 4: the conditioning of the next step (the cd slots are read in phase A of the next step only; the frame
+                // constants wait for B4: C still reads this frame's c4 in this window) ----------------
+                if (CS_COND_W4 && t + 1 < bsteps) cond_step(t + 1);
                 PBW(16);
-                __syncthreads();   // B4
+                __syncthreads();   // B4: fc2 outputs -> P
                 PBW(19);
 
-                // ---------------- window 5: conditioning of the next step ----------------
-                // (MOL: in front of B4b -- behind it the C waves only sample, 800 cycles, and then waited 775 at B5 for this)
+                // ---------------- window 5: frame constants of a new frame; this wave's half of fc3 (+ its candidate of the race, RAW) ----------------
                 if (CS_COND_W4) frame_flush(); else if (t + 1 < bsteps) cond_step(t + 1);
-                if (FC3_SPLIT) {   // this wave's half of fc3 (see the C waves' window 5)
-                    const float lg1 = fc3_one_set<NQ, D3>(w3 + 8 * 64, vP, my_rq) + cst[C_B31 * SL];
-                    if (primary) lgt[rb * 32 + cls0 + 4] = lg1;
-                    if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 + 4 < NC)
+                if (FC3_SPLIT) {   // classes 8 wl + iu + 4 (see the C waves' window 5)
+                    float lg1 = 0.f;
+                    if (wg_has_fc3) lg1 = fc3_one_set<NQ, D3>(w3 + 8 * 64, vP, my_rq) + cst[C_B31 * SL];
+                    if (MODE == WRNN_MODE_MOL && primary) lgt[rb * 32 + cls0 + 4] = lg1;
+                    if (a.logits_out && primary && row_ok && t < rw.steps && (MODE != WRNN_MODE_MOL || g == 0) && cls0 + 4 < NC)
                         a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0 + 4] = lg1;
+                    if (MODE == WRNN_MODE_RAW) {
+                        float v = cls0 + 4 < NC ? lg1 + hand[(H_NZ + 2 * par + 1) * SL] : -INFINITY;
+                        int k = cls0 + 4;
+                        race_fold(v, k);
+                        if (primary && rho == 0)
+                            st_granule(mail, L::M_PR / 2u + par * L::PRG + (unsigned)rb * 256u + (unsigned)(g * 8 + wl * 2 + 1),
+                                       (epoch << 10) | (unsigned)(k & 1023), __float_as_uint(v));
+                    }
                 }
                 PBW(17);
-                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: C's fc3 outputs of all rows are in LDS
+                if (MODE == WRNN_MODE_MOL) __syncthreads();   // B4b: the fc3 outputs of all rows are in LDS
                 if (NBC < NQ) {
                     // exchange 5 for batch row wl + 4 (RAW, 8 rows per team): the C wave of this SIMD finishes row wl meanwhile.  One row per
                     // wave instead of two one after the other in the four C waves (1 130 -> ~600 cycles at the end of the serial chain).
                     const int brow = wl + 4;
                     const unsigned tg = epoch & 0x3fffffu;
-                    u4v gq;
+                    const unsigned cb = (L::M_PR / 2u + par * L::PRG + (unsigned)brow * 256u) * 8u;
+                    u4v ga, gb;
                     unsigned spins = 0;
                     for (;;) {
-                        gq = ld_pair(mrs, (unsigned)lane * 16u, (LM::G_PR + par * LM::PRG + (unsigned)brow * 128u) * 8u);
-                        if (__all((gq.y >> 10) == tg && (gq.w >> 10) == tg) || dead) break;
+                        ga = ld_pair(mrs, (unsigned)lane * (FC3_SPLIT ? 32u : 16u), cb);
+                        gb = FC3_SPLIT ? ld_pair(mrs, (unsigned)lane * 32u, cb + 16u) : ga;
+                        if (__all((ga.y >> 10) == tg && (ga.w >> 10) == tg && (gb.y >> 10) == tg && (gb.w >> 10) == tg) || dead) break;
                         if (++spins > TB_SPIN_MAX) { dead = true; if (lane == 0) atomicExch(a.err, 28u); break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
                     float xf = a.x_forced ? a.x_forced[(size_t)t * a.n_rows + frowS[1]] : 0.0f;
                     asm volatile("" : "+v"(xf));
-                    const float va = __uint_as_float(gq.x), vb = __uint_as_float(gq.z);
-                    const bool pb = vb > va;   // equal scores: the lower slot = the lower class range wins
-                    const float best = pb ? vb : va;
-                    const int besti = (int)((pb ? gq.w : gq.y) & 1023u);
-                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_b(best)), 63));
-                    const u64 ball = __ballot(best == mx);
-                    const int src = (int)__builtin_ctzll(ball ? ball : 1ull);
-                    const int lab = __builtin_amdgcn_readlane(besti, src);
+                    const int lab = race_winner<FC3_SPLIT>(ga, gb);
                     const float x_new = 2.0f * (float)lab / ((float)NC - 1.0f) - 1.0f;   // (:235)
                     if (lane == 0) {
                         xn[brow] = a.x_forced ? xf : x_new;   // (:237)

@@ -18,3 +18,26 @@ for spec in $PHASE; do   # e.g. PHASE="2:64 4:32" (product) or "2:64:build_varia
   IFS=: read c b lib <<< "$spec"
   timeout 120 python tools/phase_profile.py $c $b 41 batch_cs $lib 2>&1 | tee -a gpurun_out/${T}_phase.txt
 done
+# DUMPCMP="product build_variants/libx.so ...": the labels of configs[2] / [4] at 41 frames (fixed seeds) must be IDENTICAL across builds whose arithmetic is the same
+if [ -n "$DUMPCMP" ]; then
+  for c in 2 4; do
+    for lib in $DUMPCMP; do
+      n=$(basename $lib .so)
+      if [ "$lib" = product ]; then cmd="python bench.py"; else cmd="python tools/ab_bench.py $lib"; fi
+      timeout 200 $cmd --config $c --frames 41 --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs --dump /tmp/dump_${c}_${n}.npz > /dev/null 2>&1
+    done
+    python - <<PY | tee -a gpurun_out/${T}_dumpcmp.txt
+import numpy as np
+libs = "$DUMPCMP".split()
+names = [l.split('/')[-1].replace('.so', '') for l in libs]
+ref = np.load('/tmp/dump_${c}_%s.npz' % names[0])
+for n in names[1:]:
+    try:
+        d = np.load('/tmp/dump_${c}_%s.npz' % n)
+        same = np.array_equal(d['labels'], ref['labels']) and np.array_equal(d['samples'], ref['samples'])
+        print('config ${c}: %s vs %s: %s (%d label mismatches)' % (n, names[0], 'IDENTICAL' if same else 'DIFFERENT', int((d['labels'] != ref['labels']).sum())))
+    except Exception as e:
+        print('config ${c}: %s: no dump (%r)' % (n, e))
+PY
+  done
+fi
