@@ -69,6 +69,13 @@
 #ifndef CS_EARLY_LOOK
 #define CS_EARLY_LOOK 8  // the full look goes out once this many of the sentinel slice's 64 lanes carry the tag (0 = all of them)
 #endif
+#ifndef CS_MINCHK
+#define CS_MINCHK (NM > 4)   // (8 rows per team: +0.3 ... +0.8 %, 4 rows: -0.3 %; round 5 session 8) the tags of a look are checked with ONE v_min3_u32 per 16-byte load, in the order the loads return (a tag is never AHEAD of the step: nobody
+                         // can publish step e + 2 into a parity while somebody still looks for step e, so "all fresh" <=> min == tag), instead of two compares + two scalar ANDs
+#endif
+#ifndef CS_PUT2
+#define CS_PUT2 (NQ == 1)    // (4 rows per team: +1.4 %, 8 rows: -0.4 %; session 8) a gathered vector goes to LDS as ds_write2_b32 from the registers the load filled
+#endif
 #ifndef CS_FLAG_POLL_SLEEP
 #define CS_FLAG_POLL_SLEEP 1   // s_sleep units between two looks at the S waves' LDS meeting flags (0 = a tight ds_read loop at the C waves' priority beside their
                                // phase-B MFMAs: -3.5 % / -4.5 %, round 5 session 5)
@@ -123,8 +130,26 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
         __builtin_amdgcn_s_sleep(1);
     }
     if (sent_cyc) *sent_cyc = (unsigned)__builtin_readcyclecounter();   // instrumented build: the sentinel wait ends here, the data look starts
-    const unsigned offs[1] = {soff};
-    gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
+    if (CS_MINCHK) {
+      for (;;) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) g[0][m] = ld_pair(rs, voff, soff + m * 4096u);
+        unsigned mn = 0xffffffffu;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { const unsigned a = mn < g[0][m].y ? mn : g[0][m].y; mn = a < g[0][m].w ? a : g[0][m].w; }   // v_min3_u32 mn, mn, y, w
+        if (__all(mn == tag) || dead) break;
+        for (;;) {
+            if (++spins > TB_SPIN_MAX) { dead = true; if ((threadIdx.x & 63) == 0) atomicExch(err, code); break; }
+            __builtin_amdgcn_s_sleep(1);
+            const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
+            if (__all(sv.y == tag && sv.w == tag)) break;
+        }
+        if (dead) break;
+      }
+    } else {
+        const unsigned offs[1] = {soff};
+        gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
+    }
 }
 
 // one set of 4 fc3 rows (A-operand image `w3s` in LDS: [8 slabs][64 lanes] f4) times the gathered fc2 outputs: the thread's folded logit
@@ -318,6 +343,22 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     typedef float __attribute__((address_space(3))) *lds_fp;
     const lds_fp hand = (lds_fp)(size_t)launder(smem_base + (unsigned)L::L_HAND * 4u + (unsigned)ci * 4u);
     const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + 2u * (unsigned)(tl & 31)) * 4u);
+    // the two values of a 16-byte load ({x, tag, z, tag}) -> two adjacent LDS words.  CS_PUT2 1: as two 4-byte stores, which hipcc merges into one
+    // ds_write2_b32 that takes x and z from where the load left them; as an 8-byte vector store every value costs a v_mov into a register pair first, and a
+    // VALU instruction of a C wave takes ~30 cycles while the S wave of its SIMD multiplies (round-4 probe) -- which is when these run
+    typedef float __attribute__((address_space(3))) *lds_fp0;
+    const unsigned gdst_addr = (unsigned)(size_t)gdst;
+    // four loads of a gathered vector (one row quad: slices wl = 0..3) -> LDS, from ONE opaque base + immediate offsets
+    auto put8 = [&](int fidx, const u4v *g4) {
+        if (CS_PUT2) {
+            const lds_fp0 q = (lds_fp0)(size_t)launder(gdst_addr + (unsigned)fidx * 4u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { q[k * 64] = __uint_as_float(g4[k].x); q[k * 64 + 1] = __uint_as_float(g4[k].z); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gdst[(fidx + k * 64) / 2] = (f2v){__uint_as_float(g4[k].x), __uint_as_float(g4[k].z)};
+        }
+    };
 
     // S-wave meeting point (epoch of the H1 each S wave has written): LDS-address-space pointers, so that the flag is stored and polled with DS
     // instructions (round-4 advisor: through generic `volatile` pointers hipcc emitted flat_store / flat_load, which the memory model does not
@@ -386,7 +427,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     GSF_ACC(17);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int h = 0; h < NM / 4; ++h) put8(0 * L::VEC + h * 2048, &gx[0][4 * h]);
                 }
                 PBW(2);
                 __syncthreads();   // B1
@@ -422,7 +463,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     gather_sf<NM>(mrs, gvoff, (LM::G_X3 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 23u GSF_TS);
                     GSF_ACC(7);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(1 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int h = 0; h < NM / 4; ++h) put8(1 * L::VEC + h * 2048, &gx[0][4 * h]);
                 }
                 PBW(9);
                 __syncthreads();   // B2
@@ -447,7 +488,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     gather_sf<NM>(mrs, gvoff, (LM::G_F1 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 24u GSF_TS);
                     GSF_ACC(12);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int h = 0; h < NM / 4; ++h) put8(2 * L::VEC + h * 2048, &gx[0][4 * h]);
                 }
                 PBW(13);
                 __syncthreads();   // B3
@@ -472,7 +513,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u GSF_TS);
                     GSF_ACC(16);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(0 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int h = 0; h < NM / 4; ++h) put8(0 * L::VEC + h * 2048, &gx[0][4 * h]);
                 }
                 PBW(18);
                 __syncthreads();   // B4
@@ -773,7 +814,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     gather_vecs<NM, 1, false>(mrs, gvoff, offs, epoch, gx, dead, a.err, 22u);
                     PBW(1);
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) gdst[(2 * L::VEC + (m >> 2) * 2048 + (m & 3) * 64) / 2] = (f2v){__uint_as_float(gx[0][m].x), __uint_as_float(gx[0][m].z)};
+                    for (int h = 0; h < NM / 4; ++h) put8(2 * L::VEC + h * 2048, &gx[0][4 * h]);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's part of H1 has left the DS queue
                     if (lane == 0) sflag[wl] = (int)epoch;
                     PBW(5);   // h1' written to LDS
