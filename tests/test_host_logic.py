@@ -210,3 +210,20 @@ def test_philox_replays_agree():
     assert a.min() > 0.0 and a.max() < 1.0
     u_top = ((np.uint32(0xFFFFFFFF) >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
     assert u_top < 1.0
+
+
+def test_counter_numbers_are_withheld_when_the_kernel_sources_changed(monkeypatch):
+    """bench.py attaches HBM traffic and MFMA-busy cycles from a STATIC counter file (profiles/r05_pmc.json: rocprofv3 --pmc passes of one session) to
+    its roofline objects.  The file records a hash of the kernel sources it was taken on; a tree whose sources hash differently gets null counters and the
+    reason, not another kernel's numbers (round-4 review: the passes had been taken seven commits before the shipped kernel)."""
+    import bench
+    pmc = bench.load_pmc()
+    assert pmc['ok'], pmc['why']      # the ritual: the committed counter file belongs to the committed kernels (re-run tools/profile_round.sh after a kernel edit)
+    assert set(pmc['configs']) >= {1, 2, 4}
+    for c in (2, 4):
+        rec = pmc['configs'][c]
+        assert 'loop_batch_cs_kernel' in rec['kernel'] and rec['mfma_busy_cycles_per_launch'] == 8 * rec['insts_mfma_per_launch']
+        assert rec['fetch_bytes_per_launch'] > 0 and rec['kt_avg_ms'] > 0
+    monkeypatch.setattr(bench, 'csrc_sha', lambda: '0' * 16)
+    stale = bench.load_pmc()
+    assert not stale['ok'] and stale['configs'] == {} and 'counters withheld' in stale['why']
