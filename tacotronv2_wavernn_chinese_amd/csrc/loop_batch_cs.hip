@@ -20,8 +20,8 @@
 // the software-pipelined MFMA loops are those of loop_batch.hip (batch_common.h).  Per step: 5 exchanges, 5 barriers (all 8 waves).
 //   window 1: C phase A, publish x2 | h1', gather x2 -> P          S gather h1' -> H1
 //   window 2: C phase B (W_ih2.x2), publish x3, gather -> Q         S W_hh1.h1' -> gh1 slots
-//   window 3: C fc1, publish, gather -> H1                          S W_hh2.(Q - P) -> gh2 slots
-//   window 4: C fc2, publish, gather -> P                           S noise of step t+1 -> nz slots (other parity)
+//   window 3: C fc1, publish, gather -> H1                          S W_hh2.(Q - P) -> gh2 slots            (RAW at 8 rows, CS_SPREAD: in window 4, and the
+//   window 4: C fc2, publish, gather -> P                           S (MOL: conditioning of step t+1)         fc2 outputs go to H1 instead of P)
 //   window 5: C fc3 + race, publish, candidates, winners -> xn      S conditioning of step t+1 -> cd / frame-constant slots
 #include "batch_common.h"
 
@@ -68,6 +68,15 @@
 #endif
 #ifndef CS_EARLY_LOOK
 #define CS_EARLY_LOOK 8  // the full look goes out once this many of the sentinel slice's 64 lanes carry the tag (0 = all of them)
+#endif
+#ifndef CS_SPREAD
+#define CS_SPREAD (MODE == WRNN_MODE_RAW && NQ == 2)   // RAW at 8 rows per team (+1.5 % with CS_SCHEDBAR; MOL at 4 rows: -7 %, its window 4 holds the conditioning; round 5 sessions 9-11):
+                         // W_hh2 . (x3 - x2) runs in window 4, where the S waves idle, instead of window 3, where the C waves' fc1 look waited for it.  The fc2 outputs are then gathered
+                         // into H1 (dead after fc2) instead of P, so that x2 (P) and x3 (Q) stay intact until the next step; fc3 reads H1.
+#endif
+#ifndef CS_SCHEDBAR
+#define CS_SCHEDBAR (MODE == WRNN_MODE_RAW && NQ == 2)   // a scheduling barrier at every phase boundary of the step (where the instrumented build has its time stamps): hipcc otherwise moves
+                         // instructions across the boundaries; RAW at 8 rows +0.7 %, MOL at 4 rows -2.8 % (session 10)
 #endif
 #ifndef CS_MINCHK
 #define CS_MINCHK (NM > 4)   // (8 rows per team: +0.3 ... +0.8 %, 4 rows: -0.3 %; round 5 session 8) the tags of a look are checked with ONE v_min3_u32 per 16-byte load, in the order the loads return (a tag is never AHEAD of the step: nobody
@@ -202,6 +211,7 @@ __device__ __forceinline__ float fc3_one_set(lds_cf4p w3s, lds_cf4p xv, int my_r
 
 #define PBW(i)                                                                 \
     do {                                                                       \
+        if (CS_SCHEDBAR && !PROF) __builtin_amdgcn_sched_barrier(0);           \
         if (PROF) {                                                            \
             __builtin_amdgcn_sched_barrier(0);                                 \
             const unsigned now_ = (unsigned)__builtin_readcyclecounter();      \
@@ -233,7 +243,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     float *lds = (float *)smem;
     int *misc_i = (int *)(lds + L::L_MISC);
     float *xn = lds + L::L_XN;
-    float *lgt = lds + L::L_LG;
+    float *lgt = lds + (CS_SPREAD ? L::L_P : L::L_LG);   // CS_SPREAD: H1 holds the fc2 outputs in window 5, P (x2) is dead there (W_hh2 ends in front of B4)
     float *molnz = lds + L::L_HAND + H_NZ * SL;   // MOL: [parity][R][16] noise of the rows' samplers (the RAW nz slots are unused there)
     static_assert(2 * R * 16 <= 4 * SL, "MOL noise fits the nz slots");
 
@@ -337,6 +347,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const lds_cf4p vP = (lds_cf4p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + (unsigned)lane * 16u);
     const lds_cf4p vQ = vP + L::VEC / 4, vH1 = vP + 2 * (L::VEC / 4);
+    const lds_cf4p vF2 = CS_SPREAD ? vH1 : vP;   // where the gathered fc2 outputs are (fc3's B operand)
     const lds_cf4p w3 = (lds_cf4p)(size_t)launder(smem_base + (unsigned)L::L_FC3 * 4u + ((unsigned)(wl * 2) * 8u * 64u + (unsigned)lane) * 16u);
     const lds_cf4p wnl = (lds_cf4p)(size_t)launder(smem_base + (unsigned)L::L_WN * 4u + ((unsigned)wl * 8u * 64u + (unsigned)lane) * 16u);
     const lds_cfp cst = (lds_cfp)(size_t)launder(smem_base + (unsigned)L::L_CST * 4u + (unsigned)ci * 4u);
@@ -513,7 +524,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u GSF_TS);
                     GSF_ACC(16);
 #pragma unroll
-                    for (int h = 0; h < NM / 4; ++h) put8(0 * L::VEC + h * 2048, &gx[0][4 * h]);
+                    for (int h = 0; h < NM / 4; ++h) put8((CS_SPREAD ? 2 : 0) * L::VEC + h * 2048, &gx[0][4 * h]);
                 }
                 PBW(18);
                 __syncthreads();   // B4
@@ -525,7 +536,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     if (FC3_SPLIT) {
                         // MOL: the 8 sets of four fc3 rows are shared between the two waves of a SIMD -- this wave evaluates classes 8 wl + iu,
                         // the S wave 8 wl + iu + 4 (the fc3 image is in LDS, so either wave can): 32 MFMAs each, side by side, instead of 64 here
-                        lg0 = fc3_one_set<NQ, D3>(w3, vP, my_rq) + cst[C_B30 * SL];
+                        lg0 = fc3_one_set<NQ, D3>(w3, vF2, my_rq) + cst[C_B30 * SL];
                         if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 < NC)
                             a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0] = lg0;
                     } else if (wg_has_fc3) {
@@ -542,7 +553,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         for (int dd = 0; dd < D3; ++dd) {
                             rwa[dd] = w3[dd * 64]; rwb[dd] = w3[(8 + dd) * 64];
 #pragma unroll
-                            for (int q = 0; q < NQ; ++q) ring[dd][q] = vP[(q * 8 + dd) * 64];
+                            for (int q = 0; q < NQ; ++q) ring[dd][q] = vF2[(q * 8 + dd) * 64];
                         }
 #pragma unroll
                         for (int S = 0; S < 8; ++S) {
@@ -553,7 +564,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                             if (S + D3 < 8) {
                                 rwa[S % D3] = w3[(S + D3) * 64]; rwb[S % D3] = w3[(8 + S + D3) * 64];
 #pragma unroll
-                                for (int q = 0; q < NQ; ++q) ring[S % D3][q] = vP[(q * 8 + S + D3) * 64];
+                                for (int q = 0; q < NQ; ++q) ring[S % D3][q] = vF2[(q * 8 + S + D3) * 64];
                             }
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -858,13 +869,8 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                     }
                     if (primary) { hand[H_GH2R * SL] = gr; hand[H_GH2Z * SL] = gz; hand[H_GH2N * SL] = gn; }
                 };
-                if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : 1)>(wv, vH1, acc1, NoMid());
-                PBW(7);
-                PBW(8);
-                __syncthreads();   // B2
-                PBW(10);
-                fold1();
-                if (!(CS_DIAG & 2)) {
+                auto whh2 = [&]() {
+                    if (CS_DIAG & 2) return;
                     f4 xq[NQ], xp[NQ], wn = wnl[0];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) { xq[q] = vQ[(q * 8) * 64]; xp[q] = vP[(q * 8) * 64]; }
@@ -892,13 +898,21 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
+                };
+                if (!(CS_DIAG & 1)) mfma_gates<NQ, 3, false, (NQ == 1 ? 2 : 1)>(wv, vH1, acc1, NoMid());
+                PBW(7);
+                PBW(8);
+                __syncthreads();   // B2
+                PBW(10);
+                fold1();
+                if (!CS_SPREAD) whh2();
                 PBW(12);
                 __syncthreads();   // B3
                 PBW(14);
-                fold2();
+                if (!CS_SPREAD) fold2();
 
                 // ---------------- window 4 (MOL: the conditioning of the next step) ----------------
+                if (CS_SPREAD) { whh2(); fold2(); }   // x2 (P) and x3 (Q) are intact: the fc2 outputs of this window go to H1
                 if (CS_COND_W4 && t + 1 < bsteps) cond_step(t + 1);   // the cd slots are read in phase A of the next step only
                 PBW(16);
                 __syncthreads();   // B4
@@ -908,7 +922,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                 // (MOL: in front of B4b -- behind it the C waves only sample, 800 cycles, and then waited 775 at B5 for this)
                 if (CS_COND_W4) frame_flush(); else if (t + 1 < bsteps) cond_step(t + 1);
                 if (FC3_SPLIT) {   // this wave's half of fc3 (see the C waves' window 5)
-                    const float lg1 = fc3_one_set<NQ, D3>(w3 + 8 * 64, vP, my_rq) + cst[C_B31 * SL];
+                    const float lg1 = fc3_one_set<NQ, D3>(w3 + 8 * 64, vF2, my_rq) + cst[C_B31 * SL];
                     if (primary) lgt[rb * 32 + cls0 + 4] = lg1;
                     if (a.logits_out && primary && row_ok && t < rw.steps && g == 0 && cls0 + 4 < NC)
                         a.logits_out[((size_t)t * a.n_rows + row) * NC + cls0 + 4] = lg1;
