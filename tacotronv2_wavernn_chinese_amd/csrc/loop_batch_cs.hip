@@ -3,9 +3,10 @@
 //
 // Why: loop_batch.hip keeps all 320 weight registers of a SIMD lane in ONE wave (512 registers), so the MFMA phases of the serial
 // chain, the shadow MFMAs (W_hh1.h1', W_hh2.h2'), noise, conditioning and the six exchange waits run one after the other in
-// one instruction stream: 832 MFMAs issue in 6 800 of a 22 300-cycle step (R = 8), and bench_micro/mfma4_probe shows that one
-// wave cannot saturate the matrix pipe anyway (8.1 cycles per 4x4x1 MFMA per wave, 4.07 per SIMD with two waves).  Here a SIMD
-// holds two waves of 256 registers with different jobs, as in loop_team2.hip:
+// one instruction stream: 832 MFMAs issue in 6 800 of a 22 300-cycle step (R = 8).  Here a SIMD holds two waves of 256 registers with
+// different jobs, as in loop_team2.hip -- NOT for matrix throughput (round 5, bench_micro/mfma4_chip: one MFMA-only wave per SIMD delivers
+// 148 TFLOP/s chip-wide, two deliver 154: the pipe is one resource per SIMD) but so that the shadow MFMAs run while the critical wave
+// waits for memory (the sentinel round trips of its exchanges):
 //   waves 0-3 "C" (critical): W_ih2 (96) + fc1 (32) + fc2 (32) weights in VGPRs, the fc3 slice in LDS: phase A (I + GRU1),
 //                             phase B (GRU2), fc1, fc2, fc3 + the race; the four gathers of the serial chain (x2, x3, fc1, fc2)
 //                             and the winners.  Nothing else: between a publish and its gather a C wave only polls.
