@@ -22,8 +22,9 @@ fatchord_version.py:267-271), whole job over all N GPUs; weak scaling (the per-G
 
 The headline fields are the selected config's.  The default run (config 1, N=1) additionally times configs[2] and [4] for a
 few steps and attaches them as `extra_configs` {"2": {...}, "4": {...}} to the same JSON line (~10 s), plus "fold_auto": ONE 5 s utterance
-in the reference's fold mode with target='auto' (one fold per XCD: single-utterance latency) and "train_step": the
-training step of the loop layers (`wrnn_train_step`) at the reference's training shape (~1 s each).  A run on N > 1
+in the reference's fold mode with target='auto' (one fold per XCD: single-utterance latency), "dm": the secondary
+dual-softmax model (deepmind_version.py:75-165; 50 000 samples) and "train_step": the training step of the loop
+layers (`wrnn_train_step`) at the reference's training shape (~1 s each).  A run on N > 1
 GPUs (config 1) attaches `extra_configs` {"3": {...}}: BASELINE configs[3] (64 clips per GPU, scatter / gather over RCCL) at that N.
 
 Extra objects on the JSON line:
