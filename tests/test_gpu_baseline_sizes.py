@@ -217,6 +217,40 @@ def test_config2_b64_t401_full_size_rows():
     assert len({lab[i, :4000].tobytes() for i in range(B)}) == B
 
 
+def test_config2_b64_t401_injected_reference_noise_rows():
+    """configs[2] at the BASELINE size on the REFERENCE-EXACT noise path: 64 utterances x mel 80x401 with injected Exp(1) draws consumed exactly as torch.multinomial consumes
+    them (fatchord_version.py:231-237) -- 110 275 x 64 x 1024 floats = 28.9 GB, drawn ON the device (288 GB of HBM: that is what they are for) from a seeded generator.  16 rows
+    (two per XCD team, rotating with ROW_ROTATION) are walked by the oracle on the same draws over all their 110 275 steps."""
+    from tacotronv2_wavernn_chinese_amd import _cabi
+    from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
+    sd = make_state_dict(0, variant='peaky')
+    B, T = 64, 401
+    L = T * 275
+    mels = make_mels(1357, B, T)
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(6401)
+    q = torch.empty((L, B, 1024), dtype=torch.float32, device='cuda')
+    for t0 in range(0, L, 8192):       # chunks: one exponential_ call per < 2^31 elements
+        q[t0:t0 + 8192].exponential_(1.0, generator=gen)
+    q.clamp_(min=1e-30)                 # exponential_ can return 0; the reference's p / q would be inf there, the log-domain race needs a finite -log q
+    m = _model(sd)
+    res = m.generate_raw(mels, False, 11000, 550, noise_mode=_cabi.NOISE_INJECTED, noise1=q)
+    assert m.last_timing['kernel'] in (_cabi.KERNEL_BATCH, _cabi.KERNEL_BATCH_CS)
+    lab, smp = res['labels'].cpu().numpy(), res['samples'].cpu().numpy()
+    del res
+    rows = sorted(8 * k + (k + ROW_ROTATION + 2 + h) % 8 for k in range(8) for h in (0, 4))
+    qr = q[:, rows].cpu().numpy()       # (L, 16, 1024): 7.2 GB on the host, the rows the oracle walks
+    del q
+    torch.cuda.empty_cache()
+    om = orc.OracleModel(sd, fast=True)
+    st = check_on_gpu_trajectory_raw(lab[rows].T, smp[rows].T, _forced_raw(om, mels, rows, qr))
+    tag = f'configs[2] B=64 T=401 injected Exp(1) (28.9 GB on the device), {_cabi.KERNEL_NAMES[m.last_timing["kernel"]]} kernel, rows {rows}'
+    for t, r, _ in st['near_ties']:
+        near_tie_truth(tag, sd, mels[rows[r]], smp[rows[r]], t, qr[t, r], lab[rows[r], t], st['ref'], r)
+    _report(tag, dict(compared=st['compared'], near_ties=[(t, rows[r], d) for t, r, d in st['near_ties']]))
+    assert st['compared'] == L * len(rows)
+
+
 def _mol_case(B, T, rows, tag):
     from tacotronv2_wavernn_chinese_amd import _cabi
     from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
