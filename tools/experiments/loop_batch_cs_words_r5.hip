@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT -- not built, not part of the product: the round-5 exchange experiment of the batch kernel (untagged words, {x2, h1'} pairs, yield tokens, S-side emptying): parity-green, 9-19 % slower than the shipped kernel.
+// Measurements: profiles/r05_batch_cs_experiments.txt; why it is kept: DESIGN.md 3.3c / 3.4.  To build it, copy it over the csrc/ file of the same base name.
+//
 // WRNN_KERNEL_BATCH_CS: the batch kernel (loop_batch.hip: R = 4*NQ rows per XCD team in lock-step on v_mfma_f32_4x4x1, the
 // reference's "all B rows advance together", fatchord_version.py:194-237) with WAVE SPECIALISATION -- two waves per SIMD.
 //

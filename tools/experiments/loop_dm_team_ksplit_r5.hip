@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT -- not built, not part of the product: the K-split O2 / O4 variant of the dual-softmax team kernel (DMT_KSPLIT; needs the matching image fill in loop_deepmind.hip and WRNN_DM_MAIL_GRANULES = 40 960): parity-green, 11.2 us per sample against 4.75.
+// Measurements: profiles/r05_batch_cs_experiments.txt; why it is kept: DESIGN.md 3.3c / 3.4.  To build it, copy it over the csrc/ file of the same base name.
+//
 // Team kernel for the dual-softmax (coarse/fine) WaveRNN of wavernn/models/deepmind_version.py, generate() :75-165
 // (SURVEY.md section 8a row A12).  Same machinery as loop_team2.hip: one team = the 32 workgroups of one XCD, fp32
 // weights resident on chip, 8-byte {tag,value} granules exchanged through the XCD's L2, double-buffered by sample
