@@ -22,7 +22,8 @@ fatchord_version.py:267-271), whole job over all N GPUs; weak scaling (the per-G
 
 The headline fields are the selected config's.  The default run (config 1, N=1) additionally times configs[2] and [4] for a
 few steps and attaches them as `extra_configs` {"2": {...}, "4": {...}} to the same JSON line (~10 s), plus "fold_auto": ONE 5 s utterance
-in the reference's fold mode with target='auto' (one fold per XCD: single-utterance latency), "dm": the secondary
+in the reference's fold mode with target='auto' (the latency-optimal fold count: single-utterance latency), "fold_hp_defaults" (the
+reference's own target 11000 / overlap 550) and "fold_per_xcd" (one fold per XCD team: rounds 4-5's 'auto'), "dm": the secondary
 dual-softmax model (deepmind_version.py:75-165; 50 000 samples) and "train_step": the training step of the loop
 layers (`wrnn_train_step`) at the reference's training shape (~1 s each).  A run on N > 1
 GPUs (config 1) attaches `extra_configs` {"3": {...}}: BASELINE configs[3] (64 clips per GPU, scatter / gather over RCCL) at that N.
@@ -79,7 +80,8 @@ CONFIGS = {1: dict(mode='RAW', bits=10, batch=1, name='configs[1]'),
 # kept as profiles/<round>_pmc.json by tools/pmc_summary.py --json: STATIC numbers of that profile session, not of this run.  The file records the
 # commit it was taken at and a hash of the kernel sources (csrc/*.hip, *.h, include/wavernn_amd.h); when the tree's sources hash differently -- a
 # kernel was edited after the last profile -- the counter fields are reported as null instead of silently describing another kernel.
-PMC_FILE = os.path.join('profiles', 'r05_pmc.json')
+PMC_FILE = next((f for f in (os.path.join('profiles', 'r06_pmc.json'), os.path.join('profiles', 'r05_pmc.json'))
+                 if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), f))), os.path.join('profiles', 'r06_pmc.json'))   # the newest counter file in the tree
 ENGINE_HZ, N_SIMD = 2.4e9, 1024      # MI355X_MICROARCH.md: 2.4 GHz peak engine clock, 256 CUs x 4 SIMDs
 
 
@@ -276,10 +278,12 @@ def train_step_leg(dev, B: int = 32, frames: int = 5, iters: int = 6) -> dict:
                                    'conditioning and targets, seeded random weights', 'loss': round(value, 6)}}
 
 
-def fold_auto_leg(dev, frames: int = T_FRAMES, reps: int = 3) -> dict:
+def fold_leg(dev, target='auto', overlap: int = 550, frames: int = T_FRAMES, reps: int = 5) -> dict:
     """The reference's own fast mode ("batched ... very fast (realtime+)", wavernn_hparams.py:55-57, fatchord_version.py:293-405) as a
-    single-utterance LATENCY figure: one 5 s clip, generate(batched=True, target='auto') = one fold per XCD team, crossfaded and
-    unfolded on the device; value = wave_len / wall time of the whole generate() call (prologue, loop, epilogue, wav file)."""
+    single-utterance LATENCY figure: one 5 s clip through generate(batched=True, target, overlap), crossfaded and unfolded on the device;
+    value = wave_len / wall time of the whole generate() call (upload, prologue, loop, epilogue, download, wav file), mean over `reps` calls.
+    target='auto': the fold count with the lowest predicted loop time (vocoder.fold_plan: 64 folds on the batch kernel for this clip);
+    target=11000: the reference's hp defaults (10 folds); target='per_xcd': one fold per XCD team on the latency kernel (rounds 4-5's 'auto')."""
     import tempfile
     import torch
     from tacotronv2_wavernn_chinese_amd.synth import DEFAULT_DIMS, make_mels, make_state_dict
@@ -291,23 +295,28 @@ def fold_auto_leg(dev, frames: int = T_FRAMES, reps: int = 3) -> dict:
     m.to(dev)
     mels = make_mels(1000, 1, frames)
     wave_len = (frames - 1) * HOP
+    per_call, loops = [], []
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, 'o.wav')
-        m.generate(mels, path, True, 'auto', 550, True, epilogue='device', seed=1)
+        m.generate(mels, path, True, target, overlap, True, epilogue='device', seed=1)
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
         for i in range(reps):
-            wav = m.generate(mels, path, True, 'auto', 550, True, epilogue='device', seed=2 + i)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / reps
+            t0 = time.perf_counter()
+            wav = m.generate(mels, path, True, target, overlap, True, epilogue='device', seed=2 + i)
+            torch.cuda.synchronize(dev)
+            per_call.append((time.perf_counter() - t0) * 1e3)
+            loops.append(m.last_timing['loop_ms'])
+    dt = float(np.mean(per_call)) * 1e-3
     tm = m.last_timing
     assert wav.shape == (wave_len,)
-    out = {'metric': 'single-utterance latency mode: audio ksamples/sec of ONE clip in fold mode, target=auto (one fold per XCD team)',
+    what = {'auto': 'target="auto" (the cost model\'s fold count)', 'per_xcd': 'target="per_xcd" (one fold per XCD team)'}.get(target, f'target={target} (the reference\'s hp defaults)')
+    out = {'metric': f'single-utterance latency mode: audio ksamples/sec of ONE clip in fold mode, {what}',
            'value': round(wave_len / dt / 1000.0, 1), 'unit': 'ksamples/s', 'steps': reps, 'warmup': 1, 'ms_per_step': round(dt * 1e3, 3), 'dtype': 'f32',
-           'config': {'workload': f'one utterance, mel 80x{frames} ({wave_len / SAMPLE_RATE:.3f} s of audio), generate(batched=True, target="auto", overlap=550), '
+           'config': {'workload': f'one utterance, mel 80x{frames} ({wave_len / SAMPLE_RATE:.3f} s of audio), generate(batched=True, target={target!r}, overlap={overlap}), '
                                   f'{tm["rows"]} folds x {tm["steps"]} loop steps, RAW 10-bit, device epilogue (crossfade + unfold), wav written',
-                      'times_real_time': round(wave_len / SAMPLE_RATE / dt, 1), 'loop_kernel_ms': round(tm['loop_ms'], 3),
-                      'prologue_ms': round(tm['prologue_ms'], 3), 'kernel': _kernel_name(tm['kernel'])}}
+                      'times_real_time': round(wave_len / SAMPLE_RATE / dt, 1), 'loop_kernel_ms': round(float(np.mean(loops)), 3),
+                      'loop_share_of_call': round(float(np.mean(loops)) / (dt * 1e3), 4), 'ms_per_call': [round(x, 3) for x in per_call],
+                      'ms_min': round(min(per_call), 3), 'prologue_ms': round(tm['prologue_ms'], 3), 'kernel': _kernel_name(tm['kernel'])}}
     del m
     torch.cuda.empty_cache()
     return out
@@ -488,7 +497,7 @@ def run_config(cfg_id: int, *, world: int, rank: int, dev, dry: bool, steps: int
     # ... and what the counters of the last profile session say (static, withheld when the kernel sources changed since: load_pmc)
     pmc = load_pmc()
     pc = pmc['configs'].get(2 if cfg_id == 3 else cfg_id) if (pmc['ok'] and T == T_FRAMES and B == cfg['batch']) else None
-    if pc is not None and _kernel_name(kernel_ran) not in pc.get('kernel', ''):
+    if pc is not None and f'loop_{_kernel_name(kernel_ran)}_kernel<' not in pc.get('kernel', ''):   # exact kernel, not a substring ('batch' is in 'batch_cs')
         pc = None
     roof['traffic'] = (pc['fetch_bytes_per_launch'] + pc['write_bytes_per_launch']) if pc else None
     # matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES of one launch / (this run's launch duration x 2.4 GHz x 1 024 SIMDs)
@@ -642,11 +651,12 @@ def main() -> int:
                     extra[str(cid)]['config'] = e['config']
                 except Exception as ex:  # an extra leg must never sink the headline
                     extra[str(cid)] = {'error': repr(ex)}
-            note('extra leg fold_auto')
-            try:
-                extra['fold_auto'] = fold_auto_leg(dev)
-            except Exception as ex:
-                extra['fold_auto'] = {'error': repr(ex)}
+            for name, tgt in (('fold_auto', 'auto'), ('fold_hp_defaults', 11000), ('fold_per_xcd', 'per_xcd')):
+                note(f'extra leg {name}')
+                try:
+                    extra[name] = fold_leg(dev, tgt)
+                except Exception as ex:
+                    extra[name] = {'error': repr(ex)}
             note('extra leg dm')
             try:
                 extra['dm'] = dm_leg(dev)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 5
+#define WRNN_ABI_VERSION 6
 
 /* mode: fatchord_version.py:98-103 */
 #define WRNN_MODE_RAW 0 /* softmax over 2**bits classes */
@@ -287,6 +287,16 @@ int wrnn_phase_cycles(wrnn_handle *h, double *out /* [8 * 32] */);
 /* n_classes (fatchord_version.py:98-101) and loop-parameter bytes (roofline) */
 int32_t wrnn_n_classes(const wrnn_handle *h);
 int64_t wrnn_loop_weight_bytes(const wrnn_handle *h);
+
+/* ABI 6.  Can the XCD-team kernels (TEAM2 / BATCH / BATCH_CS: weights resident on chip) run for this handle on its device?  Returns 1 / 0;
+ * *n_teams_out = number of 32-CU teams (8 on an MI355X in SPX mode; what the host side sizes fold counts and batches for),
+ * *why_not_out = "" or the reason (points into the handle; valid until wrnn_destroy).  Either pointer may be NULL.  When the answer is 0,
+ * WRNN_KERNEL_AUTO runs WRNN_KERNEL_SIMPLE -- reference-ordered, any dims, ~1 ms per step: slower than the reference on CPU cores -- and the
+ * host side of the binding warns about it (the reference has no equivalent: this protects wavernn_gen.py:126's one call). */
+int32_t wrnn_team_info(const wrnn_handle *h, int32_t *n_teams_out, const char **why_not_out);
+/* Test hook: on != 0 makes this handle behave as if the residency check of wrnn_create had failed (AUTO -> SIMPLE, an explicit team kernel
+ * -> WRNN_ERR_INVALID), so that the slow-path warning can be exercised on a healthy device. */
+int wrnn_debug_force_no_teams(wrnn_handle *h, int32_t on);
 
 const char *wrnn_last_error(const wrnn_handle *h);
 int32_t wrnn_abi_version(void);

@@ -24,7 +24,8 @@ KERNEL_IDS = {v: k for k, v in KERNEL_NAMES.items()}
 DTYPE_F32, DTYPE_I64 = 0, 1
 ERR_NAMES = {0: 'WRNN_OK', -1: 'WRNN_ERR_INVALID', -2: 'WRNN_ERR_HIP', -3: 'WRNN_ERR_STATE',
              -4: 'WRNN_ERR_MISSING_KEY', -5: 'WRNN_ERR_TIMEOUT', -6: 'WRNN_ERR_BUSY'}
-ABI_VERSION = 5   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding was written against
+ERR_INVALID, ERR_TIMEOUT, ERR_BUSY = -1, -5, -6
+ABI_VERSION = 6   # WRNN_ABI_VERSION of the include/wavernn_amd.h this binding was written against
 
 # every symbol include/wavernn_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wrnn_plan', 'wrnn_generate',
@@ -32,7 +33,7 @@ EXPORTED_SYMBOLS = ('wrnn_create', 'wrnn_load_weights', 'wrnn_conditioning', 'wr
                     'wrnn_abi_version', 'wrnn_destroy', 'wrnn_epilogue', 'wrnn_epilogue_rows', 'wrnn_epilogue_tables', 'wrnn_loss',
                     'wrnn_phase_profile', 'wrnn_phase_cycles', 'wrnn_train_step', 'wrnn_train_forward', 'wrnn_train_backward', 'wrnn_sync_status', 'wrnn_train_force_step_kernels',
                     'wrnn_dm_create', 'wrnn_dm_load_weights', 'wrnn_dm_generate', 'wrnn_dm_last_error', 'wrnn_dm_destroy',
-                    'wrnn_dm_set_kernel', 'wrnn_dm_sync_status')
+                    'wrnn_dm_set_kernel', 'wrnn_dm_sync_status', 'wrnn_team_info', 'wrnn_debug_force_no_teams')
 
 
 def epilogue_tables(n_classes: int, overlap: int, hop: int):
@@ -178,6 +179,10 @@ def load_library() -> C.CDLL:
     lib.wrnn_last_error.restype = C.c_char_p
     lib.wrnn_destroy.argtypes = [vp]
     lib.wrnn_destroy.restype = None
+    lib.wrnn_team_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_char_p)]
+    lib.wrnn_team_info.restype = C.c_int32
+    lib.wrnn_debug_force_no_teams.argtypes = [vp, C.c_int32]
+    lib.wrnn_debug_force_no_teams.restype = C.c_int
     lib.wrnn_dm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.wrnn_dm_create.restype = C.c_int
     lib.wrnn_dm_load_weights.argtypes = [vp, C.POINTER(TensorDesc), C.c_int32]
@@ -346,6 +351,16 @@ class NativeVocoder:
 
     def loss(self, y_hat_ptr: int, y_ptr: int, n_rows: int, out_ptr: int, stream: int):
         self._check(self.lib.wrnn_loss(self._h, y_hat_ptr, y_ptr, int(n_rows), out_ptr, stream or None))
+
+    def team_info(self) -> Tuple[bool, int, str]:
+        """(the XCD-team kernels can run for this handle, number of 32-CU teams, reason when they cannot) -- ``wrnn_team_info``."""
+        n, why = C.c_int32(), C.c_char_p()
+        ok = self.lib.wrnn_team_info(self._h, C.byref(n), C.byref(why))
+        return bool(ok), int(n.value), (why.value or b'').decode()
+
+    def debug_force_no_teams(self, on: bool):
+        """Test hook: AUTO behaves as if the team kernels' residency check had failed."""
+        self._check(self.lib.wrnn_debug_force_no_teams(self._h, int(bool(on))))
 
     def last_timing(self) -> dict:
         t = Timing()

@@ -78,6 +78,15 @@ struct TeamGate {
 };
 TeamGate g_team_gate[64];
 
+// What keeps the generate loop off the XCD-team kernels for this handle (nullptr: nothing): the co-residency check of wrnn_create, the
+// 5-frame upsampling support the team kernels are built for (pad = 2, hop <= 275), or the test hook.
+const char *loop_team_obstacle(const wrnn_handle *h) {
+    if (h->force_no_teams) return "team kernels disabled by wrnn_debug_force_no_teams (test hook)";
+    if (!h->team_ok) return h->team_why.c_str();
+    if (h->d.ND != 5 || h->d.HOP > 275) return "team kernels are built for pad=2 (5-frame upsampling support), hop <= 275";
+    return nullptr;
+}
+
 }  // namespace
 
 hipError_t wrnn_team_gate_enter(int device, hipStream_t s) {
@@ -208,6 +217,20 @@ void wrnn_destroy(wrnn_handle *h) {
 }
 
 const char *wrnn_last_error(const wrnn_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int32_t wrnn_team_info(const wrnn_handle *h, int32_t *n_teams_out, const char **why_not_out) {
+    if (!h) return 0;
+    const char *no = loop_team_obstacle(h);
+    if (n_teams_out) *n_teams_out = h->n_teams;
+    if (why_not_out) *why_not_out = no ? no : "";
+    return no ? 0 : 1;
+}
+
+int wrnn_debug_force_no_teams(wrnn_handle *h, int32_t on) {
+    if (!h) return WRNN_ERR_INVALID;
+    h->force_no_teams = on != 0;
+    return WRNN_OK;
+}
 int32_t wrnn_n_classes(const wrnn_handle *h) { return h ? h->d.NC : 0; }
 int64_t wrnn_loop_weight_bytes(const wrnn_handle *h) { return h ? h->loop_weight_bytes : 0; }
 
@@ -544,9 +567,7 @@ int wrnn_generate(wrnn_handle *h, const float *mels_dev, int32_t B, int32_t T, i
     // what the team kernels (TEAM2, BATCH) need: co-residency (checked in wrnn_create), the 5-frame upsampling support
     // of pad = 2, hop <= 275, and 1024 or fewer classes.  AUTO falls back to the any-shape kernel otherwise;
     // an explicit request for a team kernel that cannot run is an error.
-    const char *team_no = nullptr;
-    if (!h->team_ok) team_no = h->team_why.c_str();
-    else if (d.ND != 5 || d.HOP > 275) team_no = "team kernels are built for pad=2 (5-frame upsampling support), hop <= 275";
+    const char *team_no = loop_team_obstacle(h);
     if (kernel == WRNN_KERNEL_AUTO) {
         if (team_no) kernel = WRNN_KERNEL_SIMPLE;
         // one row per XCD team: the latency kernel; more rows: the batch step with critical / shadow wave roles (round 4: 7.5 against 6.85

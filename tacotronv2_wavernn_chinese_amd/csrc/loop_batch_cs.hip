@@ -75,6 +75,10 @@
                          // W_hh2 . (x3 - x2) runs in window 4, where the S waves idle, instead of window 3, where the C waves' fc1 look waited for it.  The fc2 outputs are then gathered
                          // into H1 (dead after fc2) instead of P, so that x2 (P) and x3 (Q) stay intact until the next step; fc3 reads H1.
 #endif
+#ifndef CS_SPREAD_MEET
+#define CS_SPREAD_MEET 1   // CS_SPREAD only: the C waves meet (an LDS counter read under the fc2 look) before they land fc2 outputs in H1 -- a CORRECTNESS requirement
+                           // (see window 4); 0 exists for timing A/Bs only
+#endif
 #ifndef CS_SCHEDBAR
 #define CS_SCHEDBAR (MODE == WRNN_MODE_RAW && NQ == 2)   // a scheduling barrier at every phase boundary of the step (where the instrumented build has its time stamps): hipcc otherwise moves
                          // instructions across the boundaries; RAW at 8 rows +0.7 %, MOL at 4 rows -2.8 % (session 10)
@@ -83,8 +87,18 @@
 #define CS_MINCHK (NM > 4)   // (8 rows per team: +0.3 ... +0.8 %, 4 rows: -0.3 %; round 5 session 8) the tags of a look are checked with ONE v_min3_u32 per 16-byte load, in the order the loads return (a tag is never AHEAD of the step: nobody
                          // can publish step e + 2 into a parity while somebody still looks for step e, so "all fresh" <=> min == tag), instead of two compares + two scalar ANDs
 #endif
+// PRECONDITION of CS_MINCHK (round-5 advisor): no granule of a region may carry a tag GREATER than the epoch being looked for.  Holds because (1) api.hip
+// zeroes the whole mailbox inside the team gate before every launch, (2) `epoch` only grows inside a launch (one counter across the passes of a
+// launch, never reset), (3) a parity is re-published only two steps later, behind the barriers that end the looks at the older step, and (4) 2^32 steps
+// (~5 h of one launch at 4.8 us per step) are never reached: wrnn_generate's steps are bounded by the caller's clip.  A future segment-resume or mailbox-
+// reuse path that restarts `epoch` must either zero the mailbox again or fall back to the equality check (CS_MINCHK 0).
 #ifndef CS_PUT2
-#define CS_PUT2 (NQ == 1)    // (4 rows per team: +1.4 %, 8 rows: -0.4 %; session 8) a gathered vector goes to LDS as ds_write2_b32 from the registers the load filled
+#define CS_PUT2 (NQ == 1 ? 2 : 0)   // how a gathered vector lands in LDS.  0: one ds_write_b64 per 16-byte load (a v_mov per value into a register pair first);
+                             // 1 (round 5, 4 rows per team: +1.4 % in the builder's sessions, 0 on the driver's box; 8 rows: -0.4 %): ds_write2_b32 from the registers
+                             // the load filled, the two values on ADJACENT words -- every ds_write banks (a/4) mod 32 over 32-lane groups (MI355X_MICROARCH.md, LDS), so
+                             // 32 lanes writing even words hit 16 banks twice: SQ_LDS_BANK_CONFLICT 2.2 % -> 14.9 % of the LDS-active cycles (round-5 review);
+                             // 2 (round 6): the same ds_write2_b32, conflict-free -- the producers place their granules so that the pair a lane loads belongs 32 WORDS
+                             // apart (granule 2 i + b of a 64-granule piece <-> word i + 32 b): each pass of the write2 puts 32 lanes on 32 consecutive words
 #endif
 #ifndef CS_FLAG_POLL_SLEEP
 #define CS_FLAG_POLL_SLEEP 1   // s_sleep units between two looks at the S waves' LDS meeting flags (0 = a tight ds_read loop at the C waves' priority beside their
@@ -125,9 +139,12 @@ constexpr int H_GH1R = 0, H_GH1Z = 1, H_GH1N = 2, H_CDX = 3, H_CDY = 4, H_CDZ = 
 // full look re-reads R x 4 KB per workgroup while the producers' stores queue behind those reads.  The full look
 // goes out as soon as CS_EARLY_LOOK of the sentinel slice's 64 lanes carry the step's tag: the stragglers' granules land while it is
 // in flight, so the sentinel round trip and the data round trip overlap (round 4: +2.1 % / +4.4 %).
+typedef volatile unsigned __attribute__((address_space(3))) *lds_vup;
+// `count` (optional): one LDS word read UNDER the data look -- issued behind the look's loads, so that the DS round trip is covered by the
+// L2 round trip -- and returned in *count_out for the caller to check (the C waves' meeting point of CS_SPREAD, see window 4).
 template <int NM>
 __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned tag, u4v (&g)[1][NM], bool &dead,
-                                          unsigned *err, unsigned code, unsigned *sent_cyc = nullptr) {
+                                          unsigned *err, unsigned code, unsigned *sent_cyc = nullptr, lds_vup count = nullptr, unsigned *count_out = nullptr) {
     unsigned spins = 0;
     for (;;) {
         const u4v sv = ld_pair(rs, voff, soff + (NM - 1) * 4096u);
@@ -144,6 +161,7 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
       for (;;) {
 #pragma unroll
         for (int m = 0; m < NM; ++m) g[0][m] = ld_pair(rs, voff, soff + m * 4096u);
+        if (count) *count_out = *count;
         unsigned mn = 0xffffffffu;
 #pragma unroll
         for (int m = 0; m < NM; ++m) { const unsigned a = mn < g[0][m].y ? mn : g[0][m].y; mn = a < g[0][m].w ? a : g[0][m].w; }   // v_min3_u32 mn, mn, y, w
@@ -159,6 +177,7 @@ __device__ __forceinline__ void gather_sf(__amdgpu_buffer_rsrc_t rs, unsigned vo
     } else {
         const unsigned offs[1] = {soff};
         gather_vecs<NM, 1, false>(rs, voff, offs, tag, g, dead, err, code);
+        if (count) *count_out = *count;
     }
 }
 
@@ -305,7 +324,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     // its 30 granules: one more L2 round trip on the serial chain).
     const int cls0 = (MODE == WRNN_MODE_MOL ? 0 : 32 * g) + 8 * wl + iu;
     const bool wg_has_fc3 = MODE == WRNN_MODE_MOL || 32 * g < NC;
-    const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
+    // word of this thread's (unit, row) inside its 64-word piece of a gathered vector: [iu][j][e = g & 3] (the B-operand order), and the granule that carries it
+    const unsigned mb_w = (unsigned)iu * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
+    const unsigned mb_own = (((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 64u + (CS_PUT2 == 2 ? (((mb_w & 31u) << 1) | (mb_w >> 5)) : mb_w);
     const unsigned gvoff = (unsigned)tl * 16u;
     // compact slot index of this thread's (unit, row): duplicates (kp2 >= NQ) read their primary lane's entry (an LDS broadcast)
     const int ci = (wl * 4 + rho) * (4 * NQ) + my_rq * 4 + j;
@@ -354,7 +375,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const lds_cfp cst = (lds_cfp)(size_t)launder(smem_base + (unsigned)L::L_CST * 4u + (unsigned)ci * 4u);
     typedef float __attribute__((address_space(3))) *lds_fp;
     const lds_fp hand = (lds_fp)(size_t)launder(smem_base + (unsigned)L::L_HAND * 4u + (unsigned)ci * 4u);
-    const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + 2u * (unsigned)(tl & 31)) * 4u);
+    const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + (CS_PUT2 == 2 ? 1u : 2u) * (unsigned)(tl & 31)) * 4u);
     // the two values of a 16-byte load ({x, tag, z, tag}) -> two adjacent LDS words.  CS_PUT2 1: as two 4-byte stores, which hipcc merges into one
     // ds_write2_b32 that takes x and z from where the load left them; as an 8-byte vector store every value costs a v_mov into a register pair first, and a
     // VALU instruction of a C wave takes ~30 cycles while the S wave of its SIMD multiplies (round-4 probe) -- which is when these run
@@ -365,7 +386,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
         if (CS_PUT2) {
             const lds_fp0 q = (lds_fp0)(size_t)launder(gdst_addr + (unsigned)fidx * 4u);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { q[k * 64] = __uint_as_float(g4[k].x); q[k * 64 + 1] = __uint_as_float(g4[k].z); }
+            for (int k = 0; k < 4; ++k) { q[k * 64] = __uint_as_float(g4[k].x); q[k * 64 + (CS_PUT2 == 2 ? 32 : 1)] = __uint_as_float(g4[k].z); }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) gdst[(fidx + k * 64) / 2] = (f2v){__uint_as_float(g4[k].x), __uint_as_float(g4[k].z)};
@@ -380,6 +401,9 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     typedef volatile int __attribute__((address_space(3))) *lds_vip;
     typedef volatile i4v __attribute__((address_space(3))) *lds_vi4p;
     const lds_vip sflag = (lds_vip)(size_t)(smem_base + (unsigned)(L::L_MISC + 8) * 4u);
+    // C-wave meeting point of CS_SPREAD (window 4): number of (C wave, step) pairs that have finished READING H1 as fc2's B operand
+    // (zeroed with the rest of the LDS tail above; 4 per step, `epoch` counts this workgroup's steps from 1)
+    const lds_vup ccount = (lds_vup)(size_t)(smem_base + (unsigned)(L::L_MISC + 12) * 4u);
     bool dead = false;
     unsigned epoch = 0;
     unsigned *prof_lds = (unsigned *)(lds + L::L_PROF);
@@ -517,12 +541,38 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
                         if (q == 0 || my_rq == q) s = f;
                     }
                     if (primary) st_granule(mail, LM::G_F2 + par * LM::RG + mb_own, epoch, __float_as_uint(fmaxf(s + hand[H_C4 * SL], 0.0f)));
+                    // CS_SPREAD gathers the fc2 outputs INTO H1, the vector all four C waves have just streamed as fc2's B operand.  "H1 is dead after
+                    // fc2" holds per wave, not per workgroup, and no barrier separates a sibling's reads from this wave's landing: a wave's look
+                    // covers the granules of workgroups 8 w .. 8 w + 7 only, so for three of the four waves the fresh tags say nothing about the
+                    // siblings in their OWN workgroup (round-5 advisor: the 7 M-step parity run passed on timing -- an exchange takes ~2 us, the
+                    // inter-wave skew is a fraction of that).  INVARIANT: a C wave adds 1 to `ccount` (ds_add) behind its fc2 publish -- its B-operand
+                    // reads of H1 fed the MFMAs whose fold it has just published, DS instructions of a wave execute in order, and the st_granule
+                    // asm is a compiler barrier -- and lands fc2 outputs in H1 only after reading ccount == 4 * epoch (no sibling can be a step
+                    // ahead: barriers B4 / B5 are in between).
+                    if (CS_SPREAD && CS_SPREAD_MEET && lane == 0)
+                        __hip_atomic_fetch_add((unsigned __attribute__((address_space(3))) *)ccount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 PBW(15);
                 {
                     u4v gx[1][NM];
                     GSF_DECL;
-                    gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u GSF_TS);
+                    if (CS_SPREAD && CS_SPREAD_MEET) {
+                        unsigned cc = 0;
+#if CS_PROF_SPLIT
+                        gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u, PROF ? &ts_ : nullptr, ccount, &cc);
+#else
+                        gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u, nullptr, ccount, &cc);
+#endif
+                        unsigned sp = 0;
+                        while (__builtin_amdgcn_readfirstlane(cc) != 4u * epoch && !dead) {   // normally false at once: the counter was read under the data look
+                            if (++sp > 200000u) { dead = true; if (lane == 0) atomicExch(a.err, 30u); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                            cc = *ccount;
+                        }
+                        asm volatile("" ::: "memory");
+                    } else {
+                        gather_sf<NM>(mrs, gvoff, (LM::G_F2 + par * LM::RG) * 8u, epoch, gx, dead, a.err, 25u GSF_TS);
+                    }
                     GSF_ACC(16);
 #pragma unroll
                     for (int h = 0; h < NM / 4; ++h) put8((CS_SPREAD ? 2 : 0) * L::VEC + h * 2048, &gx[0][4 * h]);

@@ -93,6 +93,7 @@ struct wrnn_handle {
     bool team_dims = false;       // the constructor dims are the reference hparams the team kernels are built for
     bool team_ok = false;         // the 32-workgroup team kernels can be co-resident on this device (checked at create)
     std::string team_why;         // why not, when team_ok is false
+    bool force_no_teams = false;  // wrnn_debug_force_no_teams: AUTO behaves as if residency had failed (tests of the slow-path warning)
     bool cs_ok = false;           // ... and loop_batch_cs_kernel in particular (AUTO falls back to WRNN_KERNEL_BATCH without it)
     float *tab = nullptr;         // CM|CA|VM|VA|C2|C3|C4 for the current batch
     size_t tab_cap = 0;

@@ -66,8 +66,9 @@ def main(argv=None):
     parser.add_argument('--batched', '-b', dest='batched', action='store_true', help='Fast Batched Generation')
     parser.add_argument('--unbatched', '-u', dest='batched', action='store_false', help='Slow Unbatched Generation')
     parser.add_argument('--samples', '-s', type=int, help='[int] number of utterances to generate')
-    parser.add_argument('--target', '-t', type=lambda s: s if s == 'auto' else int(s),
-                        help="[int] number of samples in each batch index ('auto': one fold per XCD of the GPU)")
+    parser.add_argument('--target', '-t', type=lambda s: s if s in ('auto', 'per_xcd') else int(s),
+                        help="[int] number of samples in each batch index ('auto': the fold length with the lowest predicted latency on this GPU; "
+                             "'per_xcd': one fold per XCD)")
     parser.add_argument('--overlap', '-o', type=int, help='[int] number of crossover samples')
     parser.add_argument('--file', '-f', type=str, help='[string/path] (T, n_mels) .npy mel to vocode')
     parser.add_argument('--voc_weights', '-w', type=str, help='[string/path] Load in different WaveRNN weights')

@@ -19,8 +19,10 @@ the losses of the training script live in ``losses.py``.
 """
 from __future__ import annotations
 
+import math
 import sys
 import time
+import warnings
 from pathlib import Path
 from typing import Optional, Union
 
@@ -71,6 +73,108 @@ def fold_target(total_len: int, overlap: int, n_folds: int) -> int:
     return max(-(-(int(total_len) - int(overlap)) // int(n_folds)) - int(overlap), int(overlap), 1)
 
 
+def fold_count(total_len: int, target: int, overlap: int) -> int:
+    """Number of folds ``fold_with_overlap`` cuts ``total_len`` samples into (:319-325; = ``wrnn_plan``'s rows)."""
+    num_folds, remaining = divmod(int(total_len) - int(overlap), int(target) + int(overlap))
+    return num_folds + (1 if remaining != 0 else 0)
+
+
+# Microseconds per lock-step loop step of ONE XCD team on an MI355X, by what the team runs (profiles/r06_fold_latency_{raw,mol}.txt):
+# 'team2' the latency kernel (one row per team), 'cs4' / 'cs8' the batch kernel at <= 4 / <= 8 rows per team.  Only the RATIOS matter to
+# ``fold_plan`` (it compares fold counts on one device); a device with another clock shifts all three alike.
+STEP_US = {'RAW': {'team2': 3.30, 'cs4': 5.28, 'cs8': 7.52}, 'MOL': {'team2': 3.43, 'cs4': 4.85, 'cs8': 8.16}}
+ROWS_PER_TEAM_MAX = 8   # WRNN_BATCH_MAX_ROWS
+
+
+def predicted_loop_us(rows: int, steps: int, n_teams: int, mode: str = 'RAW') -> float:
+    """Loop time ``WRNN_KERNEL_AUTO`` needs for ``rows`` rows of ``steps`` steps on ``n_teams`` XCD teams (api.hip: rows <= teams run one per
+    team on the latency kernel; more rows are spread evenly, ceil(rows / teams) <= 8 per team batch in lock-step, a team runs its batches
+    back to back)."""
+    us = STEP_US[mode]
+    if rows <= n_teams:
+        return steps * us['team2']
+    rpb = min(-(-rows // n_teams), ROWS_PER_TEAM_MAX)
+    passes = -(-(-(-rows // rpb)) // n_teams)
+    return steps * passes * (us['cs4'] if rpb <= 4 else us['cs8'])
+
+
+def fold_plan(total_len: int, overlap: int, n_teams: int = 8, mode: str = 'RAW'):
+    """The fold count that minimises the predicted loop time of ONE utterance in the reference's batched mode (``target='auto'``):
+    every count from 1 to 2 x 8 x teams is priced as steps(target, overlap) x us/step(rows per team) x passes -- fewer, longer folds
+    cost steps, more folds cost the 2 x overlap samples each one generates twice and, past 8 per team, a second pass.  On an MI355X
+    a 5 s clip lands at 64 folds (8 per team, 2 265 steps, ~17 ms) against 47 ms for one fold per team.  Returns
+    (target, folds, predicted_us); ties go to the smaller fold count (fewer crossfades)."""
+    best = None
+    for n in range(1, 2 * ROWS_PER_TEAM_MAX * max(n_teams, 1) + 1):
+        target = fold_target(total_len, overlap, n)
+        rows = fold_count(total_len, target, overlap)
+        if rows < 1:
+            continue
+        cost = predicted_loop_us(rows, target + 2 * overlap, max(n_teams, 1), mode)
+        if best is None or cost < best[2] * (1.0 - 1e-9):
+            best = (target, rows, cost)
+    if best is None:
+        raise ValueError(f'no fold plan for {total_len} samples with overlap {overlap}')
+    return best
+
+
+_CU_COUNT = {}   # torch.cuda.get_device_properties costs ~0.1 s on its first call (amdsmi): asked once per device
+
+
+def _device_teams(dev) -> int:
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _CU_COUNT:
+        _CU_COUNT[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return max(1, min(8, _CU_COUNT[idx] // 32))
+
+
+def reference_noise(mode: str, rows: int, steps: int, n_classes: int, rnn_dims: int, aux_dims: int, device, chunk_bytes: int = 64 << 20):
+    """The sampling noise of the reference's ``generate`` (:169-264) drawn from the GLOBAL torch CPU generator exactly as the reference
+    consumes it, so that ``torch.manual_seed(s); model.generate(..., noise_mode='reference')`` is the reference's own output for seed s
+    (model on the CPU there; a reference model on a CUDA device draws from that device's generator, which cannot be replayed):
+      1. ``get_gru_cell`` builds two ``nn.GRUCell`` objects whose default initialisation draws from the generator (:178-179, :273-279);
+      2. RAW: ``Categorical.sample()`` = ``torch.multinomial(p, 1, True)`` = argmax p / q with ``q = empty(rows, n_classes).exponential_(1)``,
+         one call per step (:231-235);  MOL: ``uniform_(1e-5, 1 - 1e-5)`` on (1, rows, 10) and then on (1, rows), per step
+         (``wavernn/utils/distribution.py:106,118``).
+    One generator call per step like the reference (``exponential_`` seeds a per-call stream whose content depends on the call's size),
+    written straight into a host chunk and uploaded.  Returns (noise1, noise2) device tensors laid out as ``wrnn_sample_opts`` wants them:
+    RAW (steps, rows, n_classes), None;  MOL (steps, rows, 10), (steps, rows)."""
+    device = torch.device(device)
+    pin = device.type == 'cuda'
+    nn.GRUCell(rnn_dims, rnn_dims)                 # get_gru_cell(self.rnn1): draws discarded, as in the reference
+    nn.GRUCell(rnn_dims + aux_dims, rnn_dims)      # get_gru_cell(self.rnn2)
+    width = n_classes if mode == 'RAW' else 11
+    chunk = int(max(1, min(steps, chunk_bytes // (rows * width * 4))))
+    if mode == 'RAW':
+        out1, out2 = torch.empty((steps, rows, n_classes), dtype=torch.float32, device=device), None
+        b1 = torch.empty((chunk, rows, n_classes), dtype=torch.float32, pin_memory=pin)
+        for t0 in range(0, steps, chunk):
+            n = min(chunk, steps - t0)
+            for t in range(n):
+                b1[t].exponential_(1)
+            out1[t0:t0 + n].copy_(b1[:n])
+        # exponential_ may return 0 (p / q = inf in the reference: that class wins); the log-domain race needs a finite -log q
+        out1.clamp_(min=1.2e-38)
+    else:
+        out1 = torch.empty((steps, rows, 10), dtype=torch.float32, device=device)
+        out2 = torch.empty((steps, rows), dtype=torch.float32, device=device)
+        b1 = torch.empty((chunk, 1, rows, 10), dtype=torch.float32, pin_memory=pin)
+        b2 = torch.empty((chunk, 1, rows), dtype=torch.float32, pin_memory=pin)
+        for t0 in range(0, steps, chunk):
+            n = min(chunk, steps - t0)
+            for t in range(n):
+                b1[t].uniform_(1e-5, 1.0 - 1e-5)
+                b2[t].uniform_(1e-5, 1.0 - 1e-5)
+            out1[t0:t0 + n].copy_(b1[:n, 0])
+            out2[t0:t0 + n].copy_(b2[:n, 0])
+    return out1, out2
+
+
+_NOISE_REFERENCE = -1   # host-side mode: resolved to NOISE_INJECTED with the reference's own draws before the C-ABI call
+_NOISE_MODES = {'philox': _cabi.NOISE_PHILOX, 'injected': _cabi.NOISE_INJECTED, 'argmax': _cabi.NOISE_ARGMAX, 'reference': _NOISE_REFERENCE}
+
+
 class WaveRNN(nn.Module):
     def __init__(self, rnn_dims, fc_dims, bits, pad, upsample_factors,
                  feat_dims, compute_dims, res_out_dims, res_blocks,
@@ -118,6 +222,7 @@ class WaveRNN(nn.Module):
         # backward, clipping, Adam: ~150 small launches) under the running step.  'deferred': no wait; the caller asks once per iteration
         # with ``training_status()`` (``train.voc_train_loop`` does, at its ``loss.item()``, and before it writes a checkpoint).
         self.check_device_errors = True
+        self.busy_retry_seconds = 0.05   # WRNN_ERR_BUSY under AUTO: wait this long, retry the team kernel once, then fall back (loudly)
         self.verbose = True
         self.last_timing: Optional[dict] = None
 
@@ -138,8 +243,13 @@ class WaveRNN(nn.Module):
         (``p.data.copy_()``, ``p.data.fill_()``) bump neither: call :meth:`invalidate_native` after those."""
         # `step` and BatchNorm's `num_batches_tracked` are never read by wrnn_load_weights: leaving them out keeps forward()
         # (which bumps `step` in place, :139) from repacking and re-uploading every weight on every call
-        bufs = [b for n, b in self.named_buffers() if n != 'step' and not n.endswith('num_batches_tracked')]
-        return (dev,) + tuple((id(p), p._version, p.data_ptr()) for p in list(self.parameters()) + bufs)
+        # (read from the sub-modules' own `_parameters` / `_buffers` dicts: `parameters()` + `named_buffers()` with their de-duplication
+        # sets cost 0.5 ms per call, 3 % of a 19 ms single-utterance generate)
+        objs = []
+        for m in self.modules():
+            objs.extend(m._parameters.values())
+            objs.extend(b for n, b in m._buffers.items() if n != 'step' and n != 'num_batches_tracked')
+        return (dev,) + tuple((id(p), p._version, p.data_ptr()) for p in objs if p is not None)
 
     def invalidate_native(self):
         """Force the next ``generate`` to repack the weights into the native handle."""
@@ -292,12 +402,20 @@ class WaveRNN(nn.Module):
         """Device part of generate() (:183-241).  Returns dict(samples (rows, L) float32 cuda tensor,
         labels (rows, L) int32 cuda tensor, logits or None, rows, steps).
 
+        noise_mode: ``_cabi.NOISE_PHILOX`` / ``'philox'`` (device counter RNG keyed by ``seed``), ``NOISE_INJECTED`` / ``'injected'``
+        (noise1 / noise2 given), ``NOISE_ARGMAX`` / ``'argmax'`` (RAW, greedy), or ``'reference'``: the draws the reference's own
+        ``generate`` makes from the global torch CPU generator in its own order (``reference_noise``), injected -- under
+        ``torch.manual_seed(s)`` the call then reproduces the reference's output for that seed.
         noise1/noise2/x_forced: array-likes laid out like the reference consumes them (step-major):
         RAW noise1 (L, rows, n_classes) Exp(1) draws; MOL noise1 (L, rows, 10), noise2 (L, rows).
         frames: optional (B,) valid frames per utterance of a ragged, right-zero-padded batch (``wrnn_sample_opts.frames_dev``):
         row b runs frames[b] * hop steps, the rest of its output row is left unwritten (here: zero).
         batch_rows / team2_segment: tuning knobs of the BATCH / TEAM2 kernels (0 = the library's choice).
         """
+        if isinstance(noise_mode, str):
+            if noise_mode not in _NOISE_MODES:
+                raise ValueError(f'noise_mode must be one of {sorted(_NOISE_MODES)} or a WRNN_NOISE_* id, got {noise_mode!r}')
+            noise_mode = _NOISE_MODES[noise_mode]
         nat = self.native()
         dev = torch.device('cuda', nat.device)
         with torch.cuda.device(dev):
@@ -331,26 +449,60 @@ class WaveRNN(nn.Module):
                 keep.append(t)
                 return t.data_ptr()
             nmix = self.n_classes if self.mode == 'RAW' else self.n_classes // 3
+            if noise_mode == _NOISE_REFERENCE:
+                if noise1 is not None or noise2 is not None:
+                    raise ValueError("noise_mode='reference' draws its own noise: noise1 / noise2 must be None")
+                noise1, noise2 = reference_noise(self.mode, rows, steps, self.n_classes, self.rnn_dims, self.aux_dims, dev)
+                noise_mode = _cabi.NOISE_INJECTED
             n1 = to_dev(noise1, (steps, rows, nmix))
             n2 = to_dev(noise2, (steps, rows))
             xf = to_dev(x_forced, (steps, rows))
             xi = to_dev(x_init, (rows,))
             logits = torch.empty((steps, rows, self.n_classes), dtype=torch.float32, device=dev) if want_logits else None
             stream = torch.cuda.current_stream(dev).cuda_stream
-            nat.generate(mels_t.data_ptr(), B, T, batched, target, overlap,
-                         labels_ptr=labels.data_ptr(), samples_ptr=samples.data_ptr(), stream=stream,
-                         noise_mode=noise_mode, seed=int(seed), noise1_ptr=n1, noise2_ptr=n2, x_forced_ptr=xf,
-                         logits_ptr=logits.data_ptr() if logits is not None else 0,
-                         kernel=self.kernel if kernel is None else kernel, x_init_ptr=xi, mels_padded=mels_padded,
-                         frames_ptr=fr, batch_rows=batch_rows, team2_segment=team2_segment)
-            self.last_timing = nat.last_timing()  # synchronises; surfaces device-side errors
+            want_kernel = self.kernel if kernel is None else kernel
+
+            def launch(k):
+                nat.generate(mels_t.data_ptr(), B, T, batched, target, overlap,
+                             labels_ptr=labels.data_ptr(), samples_ptr=samples.data_ptr(), stream=stream,
+                             noise_mode=noise_mode, seed=int(seed), noise1_ptr=n1, noise2_ptr=n2, x_forced_ptr=xf,
+                             logits_ptr=logits.data_ptr() if logits is not None else 0,
+                             kernel=k, x_init_ptr=xi, mels_padded=mels_padded,
+                             frames_ptr=fr, batch_rows=batch_rows, team2_segment=team2_segment)
+                return nat.last_timing()  # synchronises; surfaces device-side errors
+            try:
+                self.last_timing = launch(want_kernel)
+            except _cabi.WrnnError as e:
+                # WRNN_ERR_BUSY: a team kernel's 32 workgroups per XCD did not all become resident (another process holds CUs).  An explicit
+                # kernel request fails as it is; AUTO retries once after a moment, then runs the any-shape kernel -- loudly.
+                if e.code != _cabi.ERR_BUSY or want_kernel != _cabi.KERNEL_AUTO:
+                    raise
+                time.sleep(self.busy_retry_seconds)
+                try:
+                    self.last_timing = launch(_cabi.KERNEL_AUTO)
+                except _cabi.WrnnError as e2:
+                    if e2.code != _cabi.ERR_BUSY:
+                        raise
+                    self._warn_slow_path(f'the GPU is shared with another kernel ({e2})', steps)
+                    self.last_timing = launch(_cabi.KERNEL_SIMPLE)
+            if want_kernel == _cabi.KERNEL_AUTO and self.last_timing['kernel'] == _cabi.KERNEL_SIMPLE and not getattr(self, '_slow_warned', False):
+                self._warn_slow_path(nat.team_info()[2] or 'the team kernels cannot run on this device', steps)
             frames_dev = keep[0] if ragged else None
             del keep
         return dict(samples=samples, labels=labels, logits=logits, rows=rows, steps=steps, frames=frames_dev)
 
+    def _warn_slow_path(self, why: str, steps: int):
+        """Once per model: AUTO is running ``WRNN_KERNEL_SIMPLE`` (one workgroup per row, weights streamed every step, ~1 ms per step:
+        ~300x slower than the team kernels and slower than the reference on a few CPU cores)."""
+        if getattr(self, '_slow_warned', False):
+            return
+        self._slow_warned = True
+        warnings.warn(f'WaveRNN: generating on the any-shape fallback kernel (WRNN_KERNEL_SIMPLE), ~1 ms per sample step -- about 300x slower '
+                      f'than the XCD-team kernels ({steps} steps: ~{steps * 1e-3:.0f} s per row).  Reason: {why}.', RuntimeWarning, stacklevel=3)
+
     def epilogue_device(self, res, batched, target, overlap, mu_law, wave_len):
         """float64 tail of generate() (:243-258) on the GPU (``wrnn_epilogue``): (wave_len,) float64 cuda tensor."""
-        nat = self.native()
+        nat = self._native if self._native is not None else self.native()   # the tail reads no weights: no repack check
         dev = res['samples'].device
         with torch.cuda.device(dev):
             out = torch.empty((int(wave_len),), dtype=torch.float64, device=dev)
@@ -358,12 +510,19 @@ class WaveRNN(nn.Module):
                          overlap, mu_law, wave_len, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         return out
 
-    def fold_target_for_device(self, n_frames, overlap, device=None):
-        """``target`` that cuts one utterance into as many folds (:293-340) as the device has 32-CU teams (8 on an
-        MI355X), so that batched mode generates all folds of the utterance concurrently, one per XCD."""
+    def fold_target_for_device(self, n_frames, overlap, device=None, policy='per_xcd'):
+        """``target`` for the extension values of ``generate``'s ``target`` argument (batched mode, one utterance):
+        ``'per_xcd'``: as many folds (:293-340) as the device has 32-CU teams (8 on an MI355X), one per team on the latency kernel;
+        ``'auto'``: the fold count with the lowest predicted loop time (``fold_plan``: 8 folds per team on the batch kernel for clips
+        of a second or more -- 2.5-3x faster than ``'per_xcd'`` -- fewer for short clips, where 2 x overlap per fold dominates)."""
         dev = device if device is not None else next(self.parameters()).device
-        n = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 32)
-        return fold_target(int(n_frames) * self.hop_length, int(overlap), n)
+        n = _device_teams(dev)
+        total = int(n_frames) * self.hop_length
+        if policy == 'per_xcd':
+            return fold_target(total, int(overlap), n)
+        if policy != 'auto':
+            raise ValueError(f"target must be an int, 'auto' or 'per_xcd', got {policy!r}")
+        return fold_plan(total, int(overlap), n, self.mode)[0]
 
     def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law, epilogue='host',
                  **native_opts):
@@ -373,23 +532,24 @@ class WaveRNN(nn.Module):
         batched mode needs B == 1 (:338); MOL forces ``mu_law=False`` (:174); the return value is float64
         (:245); the model is left in train mode (:262) and a wav is always written (:260).
         Sampling draws from a device counter RNG seeded from the global torch generator, so
-        ``torch.manual_seed`` makes a call reproducible like it does for the reference.
-        ``target='auto'`` (extension, batched mode): fold length chosen so that the utterance becomes one fold per
-        XCD team of the device -- the lowest-latency way to generate a single utterance (crossfades as in the
-        reference's batched mode).
+        ``torch.manual_seed`` makes a call reproducible like it does for the reference; ``noise_mode='reference'`` instead replays
+        the reference's OWN draws from that generator (``reference_noise``): ``torch.manual_seed(s)`` + this call returns what the
+        reference's ``generate`` returns for seed s on a CPU model (labels bit-equal up to a near-tie of the sampler's race).
+        ``target='auto'`` (extension, batched mode): the fold length with the lowest predicted latency for ONE utterance on this
+        device (``fold_plan``; a 5 s clip: 64 folds of 2 265 steps on the batch kernel, ~18 ms); ``target='per_xcd'``: one fold per XCD
+        team on the latency kernel (fewest crossfades that still use the whole chip, ~48 ms).  Crossfades as in the reference's batched mode.
         ``epilogue='device'`` runs decode / unfold / fade-out on the GPU (tables built like NumPy builds them;
         identical output up to the host libm's ``pow``) instead of the float64 NumPy pass on the host.
         """
-        self.eval()
+        # (the reference calls self.eval() here, :170: BatchNorm on its running statistics.  The native prologue always folds the running
+        # statistics, whatever the flag says, so the ~70-module walk is left out; the observable state -- train mode on return, :262 -- is kept)
         mu_law = mu_law if self.mode == 'RAW' else False
         start = time.time()
         mels_t = torch.as_tensor(mels)
         wave_len = (mels_t.size(-1) - 1) * self.hop_length
         if isinstance(target, str):
-            if target != 'auto':
-                raise ValueError(f"target must be an int or 'auto', got {target!r}")
-            target = self.fold_target_for_device(mels_t.size(-1), overlap)
-        if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) == _cabi.NOISE_PHILOX:
+            target = self.fold_target_for_device(mels_t.size(-1), overlap, policy=target)
+        if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) in (_cabi.NOISE_PHILOX, 'philox'):
             native_opts['seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
         res = self.generate_raw(mels_t, batched, target, overlap, **native_opts)
         if self.verbose:
@@ -447,7 +607,7 @@ class WaveRNN(nn.Module):
         batch = np.zeros((len(arrs), self.feat_dims, tmax), np.float32)
         for i, a in enumerate(arrs):
             batch[i, :, :lens[i]] = a
-        if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) == _cabi.NOISE_PHILOX:
+        if 'seed' not in native_opts and native_opts.get('noise_mode', _cabi.NOISE_PHILOX) in (_cabi.NOISE_PHILOX, 'philox'):
             native_opts['seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
         ragged = len(set(lens)) > 1
         res = self.generate_raw(batch, False, 11000, 550, frames=np.asarray(lens, np.int32) if ragged else None, **native_opts)

@@ -225,18 +225,19 @@ def test_generate_end_to_end_wav(name, tmp_path):
             np.testing.assert_allclose(wav, fx['wav'], rtol=0, atol=1e-4)
 
 
-def test_auto_target_makes_one_fold_per_xcd(tmp_path):
-    """target='auto' (extension): the folds of one utterance map one-to-one onto the 32-CU teams; the result is
-    what the reference's batched mode gives for that explicit target (oracle epilogue on the same samples)."""
+def test_per_xcd_target_makes_one_fold_per_xcd(tmp_path):
+    """target='per_xcd' (extension; round 4-5's 'auto'): the folds of one utterance map one-to-one onto the 32-CU teams; the result is
+    what the reference's batched mode gives for that explicit target (oracle epilogue on the same samples).  ('auto' = the cost model's
+    choice: tests/test_gpu_fold_latency.py.)"""
     fx = load_case('raw_peaky_fold_t30')
     m = _model(fx)
     T, overlap = 30, 100
     mels = fx['mels'][:, :, :T]
-    target = m.fold_target_for_device(T, overlap)
+    target = m.fold_target_for_device(T, overlap, policy='per_xcd')
     n_teams = torch.cuda.get_device_properties(0).multi_processor_count // 32
     rows, steps = m.native().plan(1, T, True, target, overlap)
     assert rows == n_teams and steps == target + 2 * overlap
-    wav = m.generate(mels, tmp_path / 'a.wav', True, 'auto', overlap, True, seed=11)
+    wav = m.generate(mels, tmp_path / 'a.wav', True, 'per_xcd', overlap, True, seed=11)
     wav2 = m.generate(mels, tmp_path / 'b.wav', True, target, overlap, True, seed=11)
     np.testing.assert_array_equal(wav, wav2)
     assert wav.shape == ((T - 1) * 275,)

@@ -161,7 +161,7 @@ def test_epilogue_tables_follow_numpy():
 
 
 def test_fold_target_gives_at_most_one_fold_per_team():
-    """target='auto': the reference's fold count (:319-325) for the chosen target never exceeds the number of
+    """target='per_xcd': the reference's fold count (:319-325) for the chosen target never exceeds the number of
     teams, and uses all of them once the clip is long enough."""
     from tacotronv2_wavernn_chinese_amd.vocoder import fold_target
     for n in (8, 4, 1):
@@ -175,6 +175,63 @@ def test_fold_target_gives_at_most_one_fold_per_team():
                 assert 1 <= num_folds <= n, (n, T, overlap, target, num_folds)
                 if L >= n * 3 * overlap:
                     assert num_folds == n
+
+
+def test_fold_plan_prices_the_fold_counts_like_the_library_runs_them():
+    """target='auto' (round 6): the cost model behind it.  `fold_count` restates the reference's fold count (:319-325); `predicted_loop_us`
+    mirrors WRNN_KERNEL_AUTO's row placement (api.hip: <= teams rows on the latency kernel, else ceil(rows / teams) <= 8 rows per team batch,
+    batches back to back); `fold_plan` returns the cheapest count and reproduces the measured optimum of profiles/r06_fold_latency_raw.txt."""
+    from tacotronv2_wavernn_chinese_amd.vocoder import STEP_US, fold_count, fold_plan, fold_target, predicted_loop_us
+    for L, target, overlap in ((110275, 11000, 550), (8250, 2000, 200), (110275, 1165, 550), (5775, 550, 550), (30000, 29450, 550)):
+        num_folds, remaining = divmod(L - overlap, target + overlap)
+        assert fold_count(L, target, overlap) == num_folds + (1 if remaining else 0)
+    assert fold_count(110275, 11000, 550) == 10 and fold_count(110275, 1165, 550) == 64
+    us = STEP_US['RAW']
+    assert predicted_loop_us(8, 1000, 8) == 1000 * us['team2']
+    assert predicted_loop_us(10, 1000, 8) == 1000 * us['cs4']            # 2 rows per team in one quad
+    assert predicted_loop_us(40, 1000, 8) == 1000 * us['cs8']            # 5 rows per team: two quads
+    assert predicted_loop_us(80, 1000, 8) == 2 * 1000 * us['cs8']        # 10 batches of 8 rows on 8 teams: two passes
+    assert predicted_loop_us(3, 1000, 1) == 1000 * us['cs4']             # a one-team device (CPX-like partition)
+    target, folds, cost = fold_plan(401 * 275, 550, 8, 'RAW')
+    assert (target, folds) == (1165, 64) and abs(cost - 2265 * us['cs8']) < 1e-6
+    # the plan is never worse than one fold per team, never asks for a target below the overlap, and its count is what the reference's
+    # fold arithmetic gives for the target
+    for mode in ('RAW', 'MOL'):
+        for n_teams in (8, 4, 1):
+            for T in (21, 30, 61, 120, 401, 1200):
+                for overlap in (100, 550):
+                    L = T * 275
+                    target, folds, cost = fold_plan(L, overlap, n_teams, mode)
+                    assert target >= overlap and folds == fold_count(L, target, overlap) >= 1
+                    t1 = fold_target(L, overlap, n_teams)
+                    assert cost <= predicted_loop_us(fold_count(L, t1, overlap), t1 + 2 * overlap, n_teams, mode) + 1e-9
+
+
+def test_reference_noise_is_the_stream_the_reference_consumes():
+    """vocoder.reference_noise (PRODUCT code behind noise_mode='reference') against the test infrastructure's replay (oracle/noise.py), which the
+    fixtures' checksums pin to the draws the unmodified reference consumed when the goldens were minted -- RAW and MOL, several rows, a
+    chunk size that forces several host chunks."""
+    import torch
+    from oracle.noise import noise_checksum, noise_from_seed
+    from tacotronv2_wavernn_chinese_amd.vocoder import reference_noise
+    from tests.golden_util import GOLDEN_DIR
+    for mode, rows, steps, nc in (('RAW', 1, 24 * 275, 1024), ('RAW', 3, 300, 1024), ('MOL', 1, 24 * 275, 30), ('MOL', 2, 500, 30)):
+        want = noise_from_seed(42, mode, steps, rows)
+        torch.manual_seed(42)
+        n1, n2 = reference_noise(mode, rows, steps, nc, 512, 32, 'cpu', chunk_bytes=1 << 20)
+        if mode == 'RAW':
+            np.testing.assert_array_equal(n1.numpy(), np.maximum(want['expo'], np.float32(1.2e-38)))
+            assert n2 is None
+        else:
+            np.testing.assert_array_equal(n1.numpy(), want['u_mix'])
+            np.testing.assert_array_equal(n2.numpy(), want['u_log'])
+    # ... and straight against a fixture's checksum of the reference's stream
+    z = np.load(os.path.join(GOLDEN_DIR, 'raw_peaky_b1_t24.npz'))
+    torch.manual_seed(int(z['noise_seed']))
+    n1, _ = reference_noise('RAW', 1, 24 * 275, 1024, 512, 32, 'cpu')
+    got = noise_checksum({'expo': n1.numpy()})
+    if np.allclose(noise_checksum(noise_from_seed(int(z['noise_seed']), 'RAW', 24 * 275, 1)), z['noise_checksum'], rtol=0, atol=0):
+        np.testing.assert_allclose(got, z['noise_checksum'], rtol=0, atol=0)   # (skipped where torch's CPU RNG differs from the minting build's)
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
@@ -217,13 +274,16 @@ def test_counter_numbers_are_withheld_when_the_kernel_sources_changed(monkeypatc
     its roofline objects.  The file records a hash of the kernel sources it was taken on; a tree whose sources hash differently gets null counters and the
     reason, not another kernel's numbers (round-4 review: the passes had been taken seven commits before the shipped kernel)."""
     import bench
+    import warnings
     pmc = bench.load_pmc()
-    assert pmc['ok'], pmc['why']      # the ritual: the committed counter file belongs to the committed kernels (re-run tools/profile_round.sh after a kernel edit)
-    assert set(pmc['configs']) >= {1, 2, 4}
-    for c in (2, 4):
-        rec = pmc['configs'][c]
-        assert 'loop_batch_cs_kernel' in rec['kernel'] and rec['mfma_busy_cycles_per_launch'] == 8 * rec['insts_mfma_per_launch']
-        assert rec['fetch_bytes_per_launch'] > 0 and rec['kt_avg_ms'] > 0
+    if not pmc['ok']:   # round-5 advisor: a kernel or header edit must not fail a CPU test until somebody re-profiles; bench.py already degrades to null counters
+        warnings.warn(f'bench.py will report null counter fields: {pmc["why"]} (re-run tools/profile_round.sh on the GPU box)')
+    else:
+        assert set(pmc['configs']) >= {1, 2, 4}
+        for c in (2, 4):
+            rec = pmc['configs'][c]
+            assert 'loop_batch_cs_kernel' in rec['kernel'] and rec['mfma_busy_cycles_per_launch'] == 8 * rec['insts_mfma_per_launch']
+            assert rec['fetch_bytes_per_launch'] > 0 and rec['kt_avg_ms'] > 0
     monkeypatch.setattr(bench, 'csrc_sha', lambda: '0' * 16)
     stale = bench.load_pmc()
     assert not stale['ok'] and stale['configs'] == {} and 'counters withheld' in stale['why']
