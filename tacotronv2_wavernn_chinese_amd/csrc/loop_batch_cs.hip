@@ -93,12 +93,12 @@
 // (~5 h of one launch at 4.8 us per step) are never reached: wrnn_generate's steps are bounded by the caller's clip.  A future segment-resume or mailbox-
 // reuse path that restarts `epoch` must either zero the mailbox again or fall back to the equality check (CS_MINCHK 0).
 #ifndef CS_PUT2
-#define CS_PUT2 (NQ == 1 ? 2 : 0)   // how a gathered vector lands in LDS.  0: one ds_write_b64 per 16-byte load (a v_mov per value into a register pair first);
-                             // 1 (round 5, 4 rows per team: +1.4 % in the builder's sessions, 0 on the driver's box; 8 rows: -0.4 %): ds_write2_b32 from the registers
-                             // the load filled, the two values on ADJACENT words -- every ds_write banks (a/4) mod 32 over 32-lane groups (MI355X_MICROARCH.md, LDS), so
-                             // 32 lanes writing even words hit 16 banks twice: SQ_LDS_BANK_CONFLICT 2.2 % -> 14.9 % of the LDS-active cycles (round-5 review);
-                             // 2 (round 6): the same ds_write2_b32, conflict-free -- the producers place their granules so that the pair a lane loads belongs 32 WORDS
-                             // apart (granule 2 i + b of a 64-granule piece <-> word i + 32 b): each pass of the write2 puts 32 lanes on 32 consecutive words
+#define CS_PUT2 (NQ == 1)    // (4 rows per team: +1.4 ... +2 %, 8 rows: -0.4 %; round 5 session 8, round 6 session 3) a gathered vector goes to LDS as ds_write2_b32 from the
+                             // registers the load filled, instead of one ds_write_b64 per load behind a v_mov per value.  Its two words are adjacent, so 32 lanes hit 16 of the
+                             // 32 write banks twice (SQ_LDS_BANK_CONFLICT 14.9 % of the LDS-active cycles) -- which costs nothing that can be measured: round 6 built the
+                             // conflict-free form (producers place the pair a lane loads 32 words apart; conflicts back to 2.2 %) and it was 1.7 % SLOWER at its best
+                             // early-look threshold, 10 % slower at the shipped one -- the placement decides whose publish a sentinel lane waits for, and that is what
+                             // the step time follows (profiles/r06_batch_cs_experiments.txt)
 #endif
 #ifndef CS_FLAG_POLL_SLEEP
 #define CS_FLAG_POLL_SLEEP 1   // s_sleep units between two looks at the S waves' LDS meeting flags (0 = a tight ds_read loop at the C waves' priority beside their
@@ -324,9 +324,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     // its 30 granules: one more L2 round trip on the serial chain).
     const int cls0 = (MODE == WRNN_MODE_MOL ? 0 : 32 * g) + 8 * wl + iu;
     const bool wg_has_fc3 = MODE == WRNN_MODE_MOL || 32 * g < NC;
-    // word of this thread's (unit, row) inside its 64-word piece of a gathered vector: [iu][j][e = g & 3] (the B-operand order), and the granule that carries it
-    const unsigned mb_w = (unsigned)iu * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
-    const unsigned mb_own = (((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 64u + (CS_PUT2 == 2 ? (((mb_w & 31u) << 1) | (mb_w >> 5)) : mb_w);
+    const unsigned mb_own = ((((unsigned)my_rq * 4u + (unsigned)wl) * 8u + (unsigned)(g >> 2)) * 4u + (unsigned)iu) * 16u + (unsigned)j * 4u + (unsigned)(g & 3);
     const unsigned gvoff = (unsigned)tl * 16u;
     // compact slot index of this thread's (unit, row): duplicates (kp2 >= NQ) read their primary lane's entry (an LDS broadcast)
     const int ci = (wl * 4 + rho) * (4 * NQ) + my_rq * 4 + j;
@@ -375,7 +373,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
     const lds_cfp cst = (lds_cfp)(size_t)launder(smem_base + (unsigned)L::L_CST * 4u + (unsigned)ci * 4u);
     typedef float __attribute__((address_space(3))) *lds_fp;
     const lds_fp hand = (lds_fp)(size_t)launder(smem_base + (unsigned)L::L_HAND * 4u + (unsigned)ci * 4u);
-    const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + (CS_PUT2 == 2 ? 1u : 2u) * (unsigned)(tl & 31)) * 4u);
+    const lds_f2p gdst = (lds_f2p)(size_t)launder(smem_base + (unsigned)L::L_P * 4u + ((unsigned)(tl >> 5) * 256u + 2u * (unsigned)(tl & 31)) * 4u);
     // the two values of a 16-byte load ({x, tag, z, tag}) -> two adjacent LDS words.  CS_PUT2 1: as two 4-byte stores, which hipcc merges into one
     // ds_write2_b32 that takes x and z from where the load left them; as an 8-byte vector store every value costs a v_mov into a register pair first, and a
     // VALU instruction of a C wave takes ~30 cycles while the S wave of its SIMD multiplies (round-4 probe) -- which is when these run
@@ -386,7 +384,7 @@ __global__ void __launch_bounds__(CS_THREADS) loop_batch_cs_kernel(WrnnBatchArgs
         if (CS_PUT2) {
             const lds_fp0 q = (lds_fp0)(size_t)launder(gdst_addr + (unsigned)fidx * 4u);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { q[k * 64] = __uint_as_float(g4[k].x); q[k * 64 + (CS_PUT2 == 2 ? 32 : 1)] = __uint_as_float(g4[k].z); }
+            for (int k = 0; k < 4; ++k) { q[k * 64] = __uint_as_float(g4[k].x); q[k * 64 + 1] = __uint_as_float(g4[k].z); }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) gdst[(fidx + k * 64) / 2] = (f2v){__uint_as_float(g4[k].x), __uint_as_float(g4[k].z)};

@@ -21,12 +21,14 @@ import os
 
 import numpy as np
 
-NEAR_TIE = 2e-5       # RAW: relative gap of the two best p/q scores (round 5: tightened from 1e-4; the three near-ties observed in 7.06 M steps have
-                      # fp32 margins of 1.0e-6, 1.9e-6 and 4.5e-6)
-# How often a near-tie may happen: at most 1 + one per 100 000 compared steps (observed so far: 0 on configs[1], 1 in 882 200 on
-# configs[2]).  A near-tie picks the oracle's RUNNER-UP class, which need not be adjacent: |dlabel| at those steps is recorded
-# (bound_near_ties, parity_report) so that the distance from the north star's literal "+-1 LSB" is a tracked number.
-NEAR_TIE_RATE = 2e-6   # round 5: tightened from 1e-5 (observed: 1 in 1 764 400 = 5.7e-7 on configs[2] at T = 401, 0 everywhere else)
+NEAR_TIE = 2e-5       # RAW: relative gap of the two best p/q scores (round 5: tightened from 1e-4; the six near-ties observed so far -- see below -- have
+                      # fp32 margins of 2.0e-7 ... 6.0e-6)
+# How often a near-tie may happen: at most 1 + ceil(NEAR_TIE_RATE x compared steps) per check.  A near-tie picks the oracle's RUNNER-UP class, which need
+# not be adjacent: |dlabel| at those steps is recorded (bound_near_ties, parity_report) so that the distance from the north star's literal "+-1 LSB" is a
+# tracked number.  Observed on the shipped kernels (profiles/r05_parity.txt): configs[2] at T = 401, all 64 rows, Philox: 3 in 7 057 600 (4.3e-7 per step);
+# the same size on injected reference noise, 16 rows: 2 in 1 764 400; configs[3] at world 1: 1 in 180 400 (margin 6.0e-6); 0 in every other check
+# (configs[1] both noise modes, every T = 41 run, all MOL runs).
+NEAR_TIE_RATE = 2e-6   # round 5: tightened from 1e-5
 # The BASELINE-size tests check a subset of the rows of configs[2] / [4] over all 110 275 steps; the subset rotates with this
 # number (bumped every round) so that over the rounds every (team, position) pair is covered.  (Round 5: the BASELINE-size tests check ALL rows;
 # the rotation is kept for the quick subsets of developer sessions, PARITY_ROWS=subset.)
@@ -47,7 +49,10 @@ def parity_report(line: str) -> None:
 
 def bound_near_ties(tag: str, compared: int, near_ties) -> None:
     """Assert the near-tie RATE and record count + max |dlabel| of the near-tie steps.  near_ties: [(t, row, |dlabel|)]."""
-    allowed = 1 + int(compared * NEAR_TIE_RATE)
+    # 1 + ceil(rate x N) (round-5 advisor): with int() a 180 400-step check was allowed exactly the ONE near-tie it has (configs[3] at world 1, margin
+    # 6.0e-6) -- seed-deterministic, but any legitimate re-ordering of an fp32 sum in a kernel may flip a second tie at that size.  For N >= 500 k steps the
+    # two rules differ by at most one.
+    allowed = 1 + int(np.ceil(compared * NEAR_TIE_RATE))
     worst = max((d for _, _, d in near_ties), default=0)
     parity_report(f'{tag}: steps compared {compared}, near-tie divergences {len(near_ties)} (allowed {allowed}), max |dlabel| at a near-tie '
                   f'{worst}, identical everywhere else; near-tie steps (t, row, |dlabel|): {list(near_ties)[:8]}')

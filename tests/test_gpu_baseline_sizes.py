@@ -219,8 +219,10 @@ def test_config2_b64_t401_full_size_rows():
 
 def test_config2_b64_t401_injected_reference_noise_rows():
     """configs[2] at the BASELINE size on the REFERENCE-EXACT noise path: 64 utterances x mel 80x401 with injected Exp(1) draws consumed exactly as torch.multinomial consumes
-    them (fatchord_version.py:231-237) -- 110 275 x 64 x 1024 floats = 28.9 GB, drawn ON the device (288 GB of HBM: that is what they are for) from a seeded generator.  16 rows
-    (two per XCD team, rotating with ROW_ROTATION) are walked by the oracle on the same draws over all their 110 275 steps."""
+    them (fatchord_version.py:231-237) -- 110 275 x 64 x 1024 floats = 28.9 GB, drawn ON the device (288 GB of HBM: that is what they are for) from a seeded generator.  16 OF THE 64
+    rows (two per XCD team, rotating with ROW_ROTATION) are walked by the oracle on the same draws over all their 110 275 steps: the oracle needs its rows' draws on the HOST, 7.2 GB
+    per 16 rows -- all 64 would be four such copies + four oracle passes (~4 min of the suite) for a path whose all-rows coverage exists at T = 41
+    (test_config2_b64_injected_reference_noise_all_rows) and, with Philox noise, at T = 401 (test_config2_b64_t401_full_size_rows).  The report line says so."""
     from tacotronv2_wavernn_chinese_amd import _cabi
     from tacotronv2_wavernn_chinese_amd.synth import make_mels, make_state_dict
     sd = make_state_dict(0, variant='peaky')
@@ -244,7 +246,8 @@ def test_config2_b64_t401_injected_reference_noise_rows():
     torch.cuda.empty_cache()
     om = orc.OracleModel(sd, fast=True)
     st = check_on_gpu_trajectory_raw(lab[rows].T, smp[rows].T, _forced_raw(om, mels, rows, qr))
-    tag = f'configs[2] B=64 T=401 injected Exp(1) (28.9 GB on the device), {_cabi.KERNEL_NAMES[m.last_timing["kernel"]]} kernel, rows {rows}'
+    tag = (f'configs[2] B=64 T=401 injected Exp(1) (28.9 GB on the device), {_cabi.KERNEL_NAMES[m.last_timing["kernel"]]} kernel, 16 of 64 rows (host copy of the draws: 7.2 GB per 16 '
+           f'rows; all 64 rows are covered at T=41 on this path and at T=401 with Philox) {rows}')
     for t, r, _ in st['near_ties']:
         near_tie_truth(tag, sd, mels[rows[r]], smp[rows[r]], t, qr[t, r], lab[rows[r], t], st['ref'], r)
     _report(tag, dict(compared=st['compared'], near_ties=[(t, rows[r], d) for t, r, d in st['near_ties']]))

@@ -43,12 +43,50 @@ def census(lines):
     return c
 
 
+# --windows: the VALU instructions of a step loop by barrier window and by what they are for (round-6 census for the "16-position mapping" question:
+# which instructions are indexed by (unit, batch row) only -- 16 distinct values per wave at 4 rows per team, evaluated in all 64 lanes)
+VALU_KINDS = (('transcendental (v_exp/v_rcp/v_log/v_sqrt/v_rsq)', lambda op: op.startswith(('v_exp', 'v_rcp', 'v_log', 'v_sqrt', 'v_rsq'))),
+              ('cross-lane (permlane / dpp / readlane / bpermute: K-phase folds, reductions)', lambda op, l='': op.startswith(('v_permlane', 'v_readlane', 'v_readfirstlane', 'v_writelane')) or 'dpp' in op),
+              ('compare / select (v_cmp, v_cndmask: tag checks, argmax, masks)', lambda op: op.startswith(('v_cmp', 'v_cndmask'))),
+              ('fma / mul / add / sub (gates, folds, conditioning)', lambda op: op.startswith(('v_fma', 'v_mul', 'v_add', 'v_sub', 'v_pk_', 'v_mac', 'v_fmac'))),
+              ('moves / conversions / bit ops', lambda op: True))
+
+
+def valu_breakdown(lines):
+    out = {}
+    for l in lines:
+        st = l.strip()
+        if not st or st[0] in ';.' or st.endswith(':'):
+            continue
+        op = st.split()[0]
+        if not op.startswith('v_') or op.startswith('v_mfma'):
+            continue
+        full = st.split(';')[0]
+        for k, pred in VALU_KINDS:
+            hit = pred(op) if k[0] != 'c' or not k.startswith('cross') else (op.startswith(('v_permlane', 'v_readlane', 'v_readfirstlane', 'v_writelane')) or '_dpp' in full or 'row_' in full or 'quad_perm' in full)
+            if hit:
+                out[k] = out.get(k, 0) + 1
+                break
+    return out
+
+
+def windows(lines):
+    """Split a step loop at its workgroup barriers: [(census, valu breakdown)] per window."""
+    cuts = [i for i, l in enumerate(lines) if l.strip().startswith('s_barrier')]
+    parts, a = [], 0
+    for c in cuts + [len(lines)]:
+        parts.append(lines[a:c])
+        a = c + 1
+    return [(census(p), valu_breakdown(p)) for p in parts if p]
+
+
 def fmt(c):
     return ', '.join(f'{k} {c[k]}' for k in ['instr'] + [k for k, _ in CLASSES] if c.get(k))
 
 
 def main() -> int:
-    extra = [a for a in sys.argv[1:] if a.startswith('-')]
+    want_windows = '--windows' in sys.argv[1:]
+    extra = [a for a in sys.argv[1:] if a.startswith('-') and a != '--windows']
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, 'cs.s')
         r = subprocess.run([HIPCC, *FLAGS, *extra, '--cuda-device-only', '-S', 'loop_batch_cs.hip', '-o', asm, '-Rpass-analysis=kernel-resource-usage'],
@@ -100,6 +138,14 @@ def main() -> int:
             if sp:
                 print('      scratch traffic inside: ' + ' ; '.join(sp))
             inside += c['instr']
+            if want_windows:
+                tot = {}
+                for wi, (wc, vb) in enumerate(windows(lines[a:b + 1])):
+                    print(f'      window {wi}: instr {wc["instr"]}, mfma {wc.get("mfma", 0)}, valu {wc.get("valu", 0)}, salu {wc.get("salu", 0)}, ds {wc.get("ds", 0)}, vmem {wc.get("vmem", 0)}'
+                          + (' | valu: ' + '; '.join(f'{v} {k.split(" (")[0]}' for k, v in vb.items()) if vb else ''))
+                    for k, v in vb.items():
+                        tot[k] = tot.get(k, 0) + v
+                print('      VALU by kind over the step: ' + '; '.join(f'{v} {k}' for k, v in tot.items()))
         allc = census(lines)
         print(f'   whole kernel: {fmt(allc)}')
     return 0
