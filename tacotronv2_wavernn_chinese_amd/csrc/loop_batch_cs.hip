@@ -32,7 +32,7 @@
 // the shadow products' operands -- is recorded in profiles/r04_batch_cs_experiments.txt and no longer lives in this file.  Round 5 rebuilt the exchange
 // (untagged 4-byte words with an "empty" bit pattern as the flag, {x2, h1'} as one 8-byte pair so that the S waves never look, W_hh1 from B1 on, gate n of
 // W_hh2 on the C waves, RAW fc3 split between the waves of a SIMD, shadow waves yielding through an LDS token): parity-green and 9-19 % SLOWER in every
-// combination (profiles/r05_batch_cs_experiments.txt; the kernel is kept as tools/experiments/loop_batch_cs_words_r5.hip).  The two waves of a SIMD share ONE
+// combination (profiles/r05_batch_cs_experiments.txt; that kernel: git show e3e6332:tools/experiments/loop_batch_cs_words_r5.hip).  The two waves of a SIMD share ONE
 // matrix pipe and ONE VALU issue port: a shadow MFMA is free only beside a memory wait of the critical wave, which is where this schedule has them.
 #ifndef CS_PRIO
 #define CS_PRIO 1        // the C waves run at s_setprio 3: the two waves of a SIMD compete for issue slots, the serial chain goes first

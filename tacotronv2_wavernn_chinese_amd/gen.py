@@ -7,7 +7,8 @@ handed to ``model.generate``; the output file name pattern is the reference's (:
 
 Deliberate differences: the reference hard-overrides ``batched = False`` and
 ``device = cpu`` after parsing its flags (:76-77, :93); here ``--batched`` is honoured and the model
-runs on the MI355X.  The reference's ``.wav`` input branch is broken (undefined ``file_name``, :18-20)
+runs on the MI355X.  Extensions: ``--target auto|per_xcd``, ``--noise reference [--seed N]``
+(the reference's own noise stream: ``vocoder.reference_noise``).  The reference's ``.wav`` input branch is broken (undefined ``file_name``, :18-20)
 and needs librosa feature extraction, which is out of scope: it raises ``ValueError`` here.
 """
 from __future__ import annotations
@@ -22,7 +23,7 @@ from .hparams import hparams as hp
 from .vocoder import WaveRNN
 
 
-def gen_from_file(model: WaveRNN, load_path, save_path, batched, target, overlap):
+def gen_from_file(model: WaveRNN, load_path, save_path, batched, target, overlap, **generate_opts):
     k = model.get_step() // 1000
     load_path = str(load_path)
     if ".npy" in load_path:
@@ -41,7 +42,7 @@ def gen_from_file(model: WaveRNN, load_path, save_path, batched, target, overlap
     batch_str = f'gen_batched_target{target}_overlap{overlap}' if batched else 'gen_NOT_BATCHED'
     idx = load_path.split('/')[-1].strip().split('.')[0]
     save_str = os.path.join(str(save_path), idx + '_' + batch_str + '_' + 'step={}k'.format(k) + '.wav')
-    _ = model.generate(mel, save_str, batched, target, overlap, hp.mu_law)
+    _ = model.generate(mel, save_str, batched, target, overlap, hp.mu_law, **generate_opts)
     print('\n\nstep = {}'.format(k * 1000))
     return save_str
 
@@ -75,6 +76,10 @@ def main(argv=None):
     parser.add_argument('--gta', '-g', dest='gta', action='store_true', help='Generate from GTA testset')
     parser.add_argument('--force_cpu', '-c', action='store_true',
                         help='accepted for compatibility; this package has no CPU path and will raise')
+    parser.add_argument('--noise', choices=['philox', 'reference'], default='philox',
+                        help="extension: 'reference' replays the reference's own draws from the torch CPU generator (with --seed: the wav the "
+                             "reference script produces after torch.manual_seed(seed)); 'philox' (default) = the device counter RNG")
+    parser.add_argument('--seed', type=int, default=None, help='extension: torch.manual_seed(SEED) before generating')
     parser.add_argument('--hp_file', metavar='FILE', default=DEFAULT_HPARAMS,
                         help='The file to use for the hyperparameters')
     parser.set_defaults(batched=None)
@@ -110,7 +115,9 @@ def main(argv=None):
     if args.file:
         out_dir = './wavernn_inference_output'
         os.makedirs(out_dir, exist_ok=True)
-        gen_from_file(model, args.file, out_dir, args.batched, args.target, args.overlap)
+        if args.seed is not None:
+            torch.manual_seed(args.seed)
+        gen_from_file(model, args.file, out_dir, args.batched, args.target, args.overlap, noise_mode=args.noise)
     print('\n\nExiting...\n')
 
 

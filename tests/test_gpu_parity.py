@@ -339,6 +339,13 @@ def test_cli_and_gen_from_file_end_to_end(tmp_path):
     sr, data = wavfile.read(out)
     assert sr == 22050 and data.dtype == np.float32 and data.shape == ((24 - 1) * 275,)
     assert np.isfinite(data).all() and np.abs(data).max() <= 1.0
+    # --noise reference --seed S: the wav the reference's own script produces after torch.manual_seed(S) (the fixture was minted with seed 42)
+    out.unlink()
+    r = subprocess.run([sys.executable, os.path.join(root, 'wavernn_gen.py'), '--file', str(mel), '-w', str(ckpt), '-u', '--noise', 'reference',
+                        '--seed', str(int(fx['noise_seed']))], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sr, data = wavfile.read(out)
+    np.testing.assert_array_equal(data, fx['wav'].astype(np.float32))
     # batched flag is honoured (the reference overrides it): folded generation writes the batched file name
     r = subprocess.run([sys.executable, os.path.join(root, 'wavernn_gen.py'), '--file', str(mel), '-w', str(ckpt), '-b',
                         '-t', '2000', '-o', '200'], cwd=tmp_path, capture_output=True, text=True, timeout=600)
