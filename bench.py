@@ -278,11 +278,13 @@ def train_step_leg(dev, B: int = 32, frames: int = 5, iters: int = 6) -> dict:
                                    'conditioning and targets, seeded random weights', 'loss': round(value, 6)}}
 
 
-def fold_leg(dev, target='auto', overlap: int = 550, frames: int = T_FRAMES, reps: int = 5) -> dict:
+def fold_leg(dev, target='auto', overlap: int = 550, frames: int = T_FRAMES, reps: int = 7, warm: int = 3) -> dict:
     """The reference's own fast mode ("batched ... very fast (realtime+)", wavernn_hparams.py:55-57, fatchord_version.py:293-405) as a
     single-utterance LATENCY figure: one 5 s clip through generate(batched=True, target, overlap), crossfaded and unfolded on the device;
     value = wave_len / wall time of the whole generate() call (upload, prologue, loop, epilogue, download, wav file): the MEDIAN of `reps` calls
-    (a latency figure; every call's time, the mean and the minimum are reported next to it -- BENCH_r05 had single calls of 100 ms among 48 ms ones).
+    (a latency figure; every call's time, the mean and the minimum are reported next to it).  `warm` untimed calls first: the first calls of a fresh
+    model carry one-off stalls of 10-60 ms inside the enqueue / wait (not GC, not the wav file, loop-kernel time unchanged: the HIP runtime growing its
+    pools, profiles/r06_fold_spikes.txt) -- BENCH_r05's 65 ms "mean of 3" was one such call among 48 ms ones.
     target='auto': the fold count with the lowest predicted loop time (vocoder.fold_plan: 64 folds on the batch kernel for this clip);
     target=11000: the reference's hp defaults (10 folds); target='per_xcd': one fold per XCD team on the latency kernel (rounds 4-5's 'auto')."""
     import tempfile
@@ -299,7 +301,8 @@ def fold_leg(dev, target='auto', overlap: int = 550, frames: int = T_FRAMES, rep
     per_call, loops = [], []
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, 'o.wav')
-        m.generate(mels, path, True, target, overlap, True, epilogue='device', seed=1)
+        for i in range(warm):
+            m.generate(mels, path, True, target, overlap, True, epilogue='device', seed=100 + i)
         torch.cuda.synchronize(dev)
         for i in range(reps):
             t0 = time.perf_counter()
@@ -312,7 +315,7 @@ def fold_leg(dev, target='auto', overlap: int = 550, frames: int = T_FRAMES, rep
     assert wav.shape == (wave_len,)
     what = {'auto': 'target="auto" (the cost model\'s fold count)', 'per_xcd': 'target="per_xcd" (one fold per XCD team)'}.get(target, f'target={target} (the reference\'s hp defaults)')
     out = {'metric': f'single-utterance latency mode: audio ksamples/sec of ONE clip in fold mode, {what}',
-           'value': round(wave_len / dt / 1000.0, 1), 'unit': 'ksamples/s', 'steps': reps, 'warmup': 1, 'ms_per_step': round(dt * 1e3, 3), 'dtype': 'f32',
+           'value': round(wave_len / dt / 1000.0, 1), 'unit': 'ksamples/s', 'steps': reps, 'warmup': warm, 'ms_per_step': round(dt * 1e3, 3), 'dtype': 'f32',
            'config': {'workload': f'one utterance, mel 80x{frames} ({wave_len / SAMPLE_RATE:.3f} s of audio), generate(batched=True, target={target!r}, overlap={overlap}), '
                                   f'{tm["rows"]} folds x {tm["steps"]} loop steps, RAW 10-bit, device epilogue (crossfade + unfold), wav written',
                       'times_real_time': round(wave_len / SAMPLE_RATE / dt, 1), 'loop_kernel_ms': round(float(np.mean(loops)), 3),
