@@ -161,11 +161,32 @@ def _golden(name):
     return fx
 
 
-@pytest.mark.parametrize('name', ['raw_peaky_b1_t24', 'raw_peaky_fold_t30', 'mol_default_b1_t24', 'raw_peaky_b1_t401'])
+_RNG_OK = None
+
+
+def _same_rng_stream_as_the_minting_build():
+    """The goldens pin torch's CPU generator stream of the build they were minted with (a checksum of the draws in every fixture); on a box whose torch
+    draws differently the comparison below would be against another noise sequence: skip, like tests/golden_util.load_case does."""
+    global _RNG_OK
+    if _RNG_OK is None:
+        from tacotronv2_wavernn_chinese_amd.vocoder import reference_noise
+        z = np.load(os.path.join(GOLDEN_DIR, 'raw_peaky_b1_t24.npz'))
+        state = torch.get_rng_state()
+        torch.manual_seed(int(z['noise_seed']))
+        q = reference_noise('RAW', 1, 24 * 275, 1024, 512, 32, 'cpu')[0].numpy()
+        torch.set_rng_state(state)
+        got = np.concatenate([q.reshape(-1)[:8].astype(np.float64), [q.astype(np.float64).sum()]])   # = oracle.noise.noise_checksum of {'expo': q}
+        _RNG_OK = bool(np.allclose(got, z['noise_checksum'], rtol=0, atol=0))
+    return _RNG_OK
+
+
+@pytest.mark.parametrize('name', ['raw_peaky_b1_t24', 'raw_peaky_fold_t30', 'raw_peaky_b3_t21', 'mol_default_b1_t24', 'mol_default_b2_t21', 'raw_peaky_b1_t401'])
 def test_reference_noise_mode_reproduces_the_reference(name, tmp_path):
     """`torch.manual_seed(s); generate(..., noise_mode='reference')` IS the reference's `generate` for seed s: the draws of the global CPU
     generator are replayed by the PRODUCT (vocoder.reference_noise), in the reference's order (:178-179, :231-235 / distribution.py:106,118).
     Compared with the wav (and labels) the unmodified reference produced (oracle/make_golden.py, NOISE_SEED = 42)."""
+    if not _same_rng_stream_as_the_minting_build():
+        pytest.skip('torch CPU RNG stream differs from the one the goldens were minted with')
     fx = _golden(name)
     m = _model(fx['state_dict'], mode=fx['mode'], bits=int(fx['bits']))
     args = (fx['mels'], tmp_path / 'o.wav', bool(fx['batched']), int(fx['target']), int(fx['overlap']), True)
