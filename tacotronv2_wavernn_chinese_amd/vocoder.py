@@ -98,17 +98,19 @@ def predicted_loop_us(rows: int, steps: int, n_teams: int, mode: str = 'RAW') ->
     return steps * passes * (us['cs4'] if rpb <= 4 else us['cs8'])
 
 
-def fold_plan(total_len: int, overlap: int, n_teams: int = 8, mode: str = 'RAW'):
+def fold_plan(total_len: int, overlap: int, n_teams: int = 8, mode: str = 'RAW', min_target: int = 0):
     """The fold count that minimises the predicted loop time of ONE utterance in the reference's batched mode (``target='auto'``):
     every count from 1 to 2 x 8 x teams is priced as steps(target, overlap) x us/step(rows per team) x passes -- fewer, longer folds
     cost steps, more folds cost the 2 x overlap samples each one generates twice and, past 8 per team, a second pass.  On an MI355X
     a 5 s clip lands at 64 folds (8 per team, 2 265 steps, ~17 ms) against 47 ms for one fold per team.  Returns
-    (target, folds, predicted_us); ties go to the smaller fold count (fewer crossfades)."""
+    (target, folds, predicted_us); ties go to the smaller fold count (fewer crossfades).  ``min_target`` bounds the crossfade DENSITY
+    from below (the latency optimum of a 5 s clip is a 550-sample crossfade every 1 715 samples: a third of the audio lies inside one;
+    ``min_target=5500`` gives 18 folds / 35 ms instead of 64 / 17 ms); a one-fold plan is always admissible."""
     best = None
     for n in range(1, 2 * ROWS_PER_TEAM_MAX * max(n_teams, 1) + 1):
         target = fold_target(total_len, overlap, n)
         rows = fold_count(total_len, target, overlap)
-        if rows < 1:
+        if rows < 1 or (target < min_target and n > 1):
             continue
         cost = predicted_loop_us(rows, target + 2 * overlap, max(n_teams, 1), mode)
         if best is None or cost < best[2] * (1.0 - 1e-9):
@@ -222,6 +224,7 @@ class WaveRNN(nn.Module):
         # backward, clipping, Adam: ~150 small launches) under the running step.  'deferred': no wait; the caller asks once per iteration
         # with ``training_status()`` (``train.voc_train_loop`` does, at its ``loss.item()``, and before it writes a checkpoint).
         self.check_device_errors = True
+        self.fold_min_target = 0          # target='auto': never plan folds shorter than this many samples (0: latency optimum, see fold_plan)
         self.busy_retry_seconds = 0.05   # WRNN_ERR_BUSY under AUTO: wait this long, retry the team kernel once, then fall back (loudly)
         self.verbose = True
         self.last_timing: Optional[dict] = None
@@ -522,7 +525,7 @@ class WaveRNN(nn.Module):
             return fold_target(total, int(overlap), n)
         if policy != 'auto':
             raise ValueError(f"target must be an int, 'auto' or 'per_xcd', got {policy!r}")
-        return fold_plan(total, int(overlap), n, self.mode)[0]
+        return fold_plan(total, int(overlap), n, self.mode, int(self.fold_min_target))[0]
 
     def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law, epilogue='host',
                  **native_opts):

@@ -194,6 +194,10 @@ def test_fold_plan_prices_the_fold_counts_like_the_library_runs_them():
     assert predicted_loop_us(3, 1000, 1) == 1000 * us['cs4']             # a one-team device (CPX-like partition)
     target, folds, cost = fold_plan(401 * 275, 550, 8, 'RAW')
     assert (target, folds) == (1165, 64) and abs(cost - 2265 * us['cs8']) < 1e-6
+    # min_target bounds the crossfade density from below; the latency optimum is what 0 gives
+    t2, f2, c2 = fold_plan(401 * 275, 550, 8, 'RAW', min_target=5500)
+    assert t2 >= 5500 and f2 < folds and c2 > cost and f2 == fold_count(401 * 275, t2, 550)
+    assert fold_plan(21 * 275, 550, 8, 'RAW', min_target=10 ** 9)[1] == 1          # nothing admissible but one fold
     # the plan is never worse than one fold per team, never asks for a target below the overlap, and its count is what the reference's
     # fold arithmetic gives for the target
     for mode in ('RAW', 'MOL'):
